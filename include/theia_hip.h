@@ -1,0 +1,244 @@
+/*
+ * theia_hip.h -- C ABI of libtheia_hip.so: hand-written HIP (gfx950 / CDNA4) kernels for the Theia
+ * distillation hot path (student ViT forward/backward, lconv translator heads, feature-matching loss).
+ *
+ * The reference (bdaiinstitute/theia) is pure Python and has NO native/FFI interface for this path
+ * (SURVEY.md sec. 2b, 8b): the seam it offers is the nn.Module API (models/rvfm.py:94-185).  This header is
+ * therefore the NEW boundary underneath that API; every entry point names the reference call site whose
+ * ATen/cuDNN/cuBLAS kernels it replaces (paths relative to /root/reference/src/theia unless absolute).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; all pointers are DEVICE pointers unless noted "host".
+ *   - no allocation, no ownership transfer: the caller (PyTorch on the host side) owns every buffer.
+ *   - every function enqueues work on `stream` (a hipStream_t passed as void*) and never synchronises.
+ *   - return 0 on success, negative THEIA_ERR_* otherwise; theia_last_error() gives a thread-local message.
+ *   - `dtype` selects the activation/operand element type: THEIA_F32 (exact-f32 MFMA path: parity mode) or
+ *     THEIA_BF16 (bf16 operands, f32 accumulate: throughput mode).  Reductions / statistics are always f32.
+ *   - activations are token-major / NHWC: [rows, channels] with channels contiguous.
+ */
+#ifndef THEIA_HIP_H_
+#define THEIA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define THEIA_ABI_VERSION 1
+
+enum { THEIA_OK = 0, THEIA_ERR_INVALID = -1, THEIA_ERR_LAUNCH = -2, THEIA_ERR_UNSUPPORTED = -3 };
+enum { THEIA_F32 = 0, THEIA_BF16 = 1 };
+
+int theia_abi_version(void);
+const char* theia_last_error(void);
+/* element size in bytes of a THEIA_* dtype */
+int theia_dtype_size(int dtype);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row map: how GEMM row m of the (implicitly gathered) activation operand and of the output is found.
+ *   rows per image R = rows_h*rows_w;  img = m / R;  (ry, rx) = divmod(m % R, rows_w)
+ *   input pixel of tap t : (iy, ix) = (ry*in_sy + dy[t], rx*in_sx + dx[t]);  zero if outside in_h x in_w
+ *   input address        : a + img*in_batch_stride + in_offset + (iy*in_w + ix)*in_c + ci
+ *   K index              : k = t*in_c + ci     (weights use slot wslot[t]: column wslot[t]*in_c + ci)
+ *   output pixel         : (oy, ox) = (ry*out_sy + out_y0, rx*out_sx + out_x0)
+ *   output address       : out + img*out_batch_stride + out_offset + (oy*out_w + ox)*ldo + n
+ * A plain row-major matrix is the degenerate case rows_h = rows_w = in_h = in_w = out_w = 1, ntaps = 1,
+ * in_batch_stride = lda, out_batch_stride = ldo.
+ * This one descriptor expresses nn.Linear, Conv2d 3x3 p1, ConvTranspose2d (stride 1, and stride 2 split in
+ * output-parity classes), and all of their data-gradients  (adapter_heads.py:279-327).
+ * ---------------------------------------------------------------------------------------------- */
+#define THEIA_MAX_TAPS 9
+typedef struct theia_rowmap {
+    int32_t ntaps;
+    int32_t dy[THEIA_MAX_TAPS];
+    int32_t dx[THEIA_MAX_TAPS];
+    int32_t wslot[THEIA_MAX_TAPS];
+    int32_t rows_h, rows_w;
+    int32_t in_h, in_w;
+    int32_t in_sy, in_sx;
+    int32_t in_c;
+    int32_t out_w, out_sy, out_sx, out_y0, out_x0;
+    int64_t in_batch_stride, in_offset;
+    int64_t out_batch_stride, out_offset;
+} theia_rowmap_t;
+
+/* epilogue activation selector for theia_gemm_nt */
+enum {
+    THEIA_ACT_NONE = 0,
+    THEIA_ACT_GELU = 1,      /* out = gelu_erf(v); if aux_out != NULL it receives v (pre-activation) */
+    THEIA_ACT_RELU = 2,      /* out = max(v, 0) */
+    THEIA_ACT_MUL_DGELU = 3, /* out = v * gelu_erf'(aux_in)   (backward of FC1's GELU) */
+    THEIA_ACT_MUL_DRELU = 4  /* out = v * (aux_in > 0) */
+};
+
+/*
+ * out[m, n] = act( sum_k A[m, k] * W[n, k] + bias[n] + rowtab[m % rowtab_period, n] ) + resid[m, n]
+ *
+ * A is gathered through `map` (see above); W is row-major [N, ldw] with K contiguous (the nn.Linear layout,
+ * and the packed [co][slot][ci] layout produced by theia_pack_conv_weight for convolutions).
+ * MFMA: v_mfma_f32_16x16x32_bf16 (bf16) / v_mfma_f32_16x16x4_f32 (f32), LDS-staged 128x128 tiles.
+ * Replaces: aten::addmm / aten::linear of HF ViT (transformers modeling_vit.py:202-205,246-247),
+ * aten::convolution of Conv2d / ConvTranspose2d and the head Linear (adapter_heads.py:282-288,307-326),
+ * the patch-embedding conv (modeling_vit.py:60,69) and every data-gradient of those.
+ * Requirements: K % 8 == 0 (bf16) / % 4 (f32); N % 8 == 0; in_c % 64 == 0 (bf16) / % 32 (f32) when ntaps > 1.
+ */
+typedef struct theia_gemm_args {
+    const void* a;
+    const void* w;
+    void* out;
+    const float* bias;    /* [N] or NULL */
+    const void* resid;    /* dtype elements, output-indexed, or NULL */
+    const void* aux_in;   /* dtype elements, output-indexed (ACT_MUL_*) or NULL */
+    void* aux_out;        /* dtype elements, output-indexed (ACT_GELU pre-activation) or NULL */
+    const float* rowtab;  /* f32 [rowtab_period, N] or NULL */
+    int32_t rowtab_period;
+    int32_t M, N, K;
+    int32_t ldw;
+    int32_t ldo;
+    int32_t act;
+    theia_rowmap_t map;
+} theia_gemm_args_t;
+
+int theia_gemm_nt(const theia_gemm_args_t* args, int dtype, void* stream);
+
+/*
+ * Weight gradient:  slab[s][n][wslot[t]*in_c + ci] = sum_{m in split s} dY[m, n] * A[m, (t, ci)]
+ * dY is read through the OUTPUT side of `map` (where the forward wrote), A through the INPUT side.
+ * `slabs` is f32 [splits][N][kslots*in_c]; reduce + layout-permute with theia_wgrad_reduce.
+ * bf16 operands are transposed on the fly with ds_read_b64_tr_b16; f32 uses v_mfma_f32_16x16x4_f32.
+ * Replaces: the weight-gradient half of convolution_backward / addmm backward (autograd of the above).
+ * Requirements: N % 8 == 0, in_c % 64 == 0.
+ */
+typedef struct theia_wgrad_args {
+    const void* dy;
+    const void* a;
+    float* slabs;
+    int32_t M, N;
+    int32_t ldo;     /* channels per output pixel of dY (= N for dense outputs) */
+    int32_t kslots;  /* weight slots in the slab row: row length = kslots*in_c */
+    int32_t splits;
+    theia_rowmap_t map;
+} theia_wgrad_args_t;
+
+int theia_gemm_wgrad(const theia_wgrad_args_t* args, int dtype, void* stream);
+/* recommended number of M-splits for (M, N, kslots*in_c) so that the launch fills 256 CUs */
+int theia_wgrad_splits(int M, int N, int Ktot);
+
+/* out[n*sn + slot*ss + ci*sc] (+)= sum_s slab[s][n][slot*C + ci]   (f32; permutes into the PyTorch layout) */
+int theia_wgrad_reduce(const float* slabs, int splits, int N, int kslots, int C, float* out, int64_t sn,
+                       int64_t ss, int64_t sc, int accumulate, void* stream);
+
+/* out[n] (+)= sum_m x[m*ld + n]   (bias gradients; x has `dtype` elements, out f32)  */
+int theia_colsum(const void* x, int64_t M, int N, int64_t ld, float* out, float* workspace, int accumulate,
+                 int dtype, void* stream);
+size_t theia_colsum_workspace_bytes(int64_t M, int N);
+
+/* ------------------------------------------------------------------------------------------------
+ * Parameter preparation (fp32 master weights in the reference state_dict layout -> operand layouts)
+ * ---------------------------------------------------------------------------------------------- */
+/* dst[i] = cast(src[i]) ; dst has `dtype` elements */
+int theia_cast(const float* src, void* dst, int64_t n, int dtype, void* stream);
+/* dst[c*ldd + r] = cast(src[r*C + c]) for a row-major [R, C] f32 matrix (W^T for data-gradients; ldd >= R lets
+ * several transposes share one destination, e.g. q|k|v -> [D, 3D]) */
+int theia_cast_transpose(const float* src, void* dst, int R, int C, int64_t ldd, int dtype, void* stream);
+/* generic 3-D permuting cast: dst[(i*d1 + j)*d2 + k] = cast(src[i*s0 + j*s1 + k*s2])
+ * (Conv2d [co,ci,3,3] / ConvTranspose2d [ci,co,3,3] -> packed [n][slot][c]; LN affine [C,H,W] -> [HW,C]) */
+int theia_cast_permute3(const float* src, void* dst, int d0, int d1, int d2, int64_t s0, int64_t s1,
+                        int64_t s2, int dtype, void* stream);
+/* f32 -> f32 version writing with destination strides: dst[i*t0 + j*t1 + k*t2] (+)= src[(i*d1+j)*d2+k] */
+int theia_unpermute3_f32(const float* src, float* dst, int d0, int d1, int d2, int64_t t0, int64_t t1,
+                         int64_t t2, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1: image ingest.  uint8 [b,224,224,3] (channels_last=1) or [b,3,224,224] (0) -> patch matrix
+ * [b*196, 768] with K index c*256 + ky*16 + kx, through a [3][256] f32 look-up table that reproduces the
+ * HF processor's rescale+normalize arithmetic bit-exactly (backbones.py:337-339).
+ * ---------------------------------------------------------------------------------------------- */
+int theia_patchify_u8(const uint8_t* img, const float* lut, void* out, int b, int channels_last, int dtype,
+                      void* stream);
+/* h[b, 0, :] = cls + pos[0]  (token 0 of every image; modeling_vit.py:148-149,159) */
+int theia_write_cls(const float* cls, const float* pos, void* h, int b, int ntok, int D, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2: row LayerNorm over the last dim (eps 1e-12 in the ViT; modeling_vit.py:261-262,348)
+ * ---------------------------------------------------------------------------------------------- */
+int theia_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                        float* rstd, int64_t M, int D, float eps, int dtype, void* stream);
+/* dx = LNbwd(dy) (+ dresid if non-NULL);  dgamma/dbeta (f32 [D]) (+)= reduction over rows.
+ * workspace: theia_layernorm_bwd_workspace_bytes(M, D) */
+int theia_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                        const void* dresid, void* dx, float* dgamma, float* dbeta, float* workspace,
+                        int64_t M, int D, int accumulate, int dtype, void* stream);
+size_t theia_layernorm_bwd_workspace_bytes(int64_t M, int D);
+
+/* ------------------------------------------------------------------------------------------------
+ * K11: whole-sample LayerNorm over (C,H,W) with elementwise affine (adapter_heads.py:306-324), NHWC.
+ * x, y: [b, E] with E = H*W*C; gamma/beta f32 [E] already permuted to [HW, C]; stats f32 [b, 2] = (mean, rstd).
+ * workspace: theia_layernorm_chw_workspace_bytes(b, E)
+ * ---------------------------------------------------------------------------------------------- */
+int theia_layernorm_chw_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                            float* workspace, int b, int64_t E, float eps, int dtype, void* stream);
+/* dx = LNbwd(dy) * (relu_mask ? (x > 0) : 1): the optional mask folds the backward of the ReLU that produced x.
+ * dgamma/dbeta f32 [E] (+)= sum over the batch of dy*xhat / dy. */
+int theia_layernorm_chw_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
+                            float* dgamma, float* dbeta, float* workspace, int b, int64_t E, int relu_mask,
+                            int accumulate, int dtype, void* stream);
+size_t theia_layernorm_chw_workspace_bytes(int b, int64_t E);
+
+/* ------------------------------------------------------------------------------------------------
+ * K4: multi-head self-attention softmax(Q K^T / sqrt(dh)) V, dh = 64, whole sequence per workgroup
+ * (modeling_vit.py:164-189).  qkv: [b, n, 3*D] (q | k | v, heads contiguous inside each);  o: [b, n, D];
+ * lse: f32 [b, h, n] (log-sum-exp of the scaled scores, saved for backward).
+ * ---------------------------------------------------------------------------------------------- */
+int theia_attention_fwd(const void* qkv, void* o, float* lse, int b, int n, int h, int dtype, void* stream);
+int theia_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv,
+                        float* delta_ws, int b, int n, int h, int dtype, void* stream);
+size_t theia_attention_bwd_workspace_bytes(int b, int n, int h);
+
+/* ------------------------------------------------------------------------------------------------
+ * K13: feature-matching losses of one teacher (models/rvfm.py:153-176): pred [b, E] (dtype), target [b, E] (f32).
+ * fwd:  losses[0..2] = (mse, cos, smooth_l1);  coef f32 [b, 2] per-sample cosine-gradient coefficients.
+ * bwd:  dpred = w[0]*d mse/dpred + w[1]*d cos/dpred + w[2]*d l1/dpred, w = 3 f32 on the device.
+ * workspace: theia_distill_loss_workspace_bytes(b, E)
+ * ---------------------------------------------------------------------------------------------- */
+int theia_distill_loss_fwd(const void* pred, const float* target, float* losses, float* coef, float* workspace,
+                           int b, int64_t E, int dtype, void* stream);
+int theia_distill_loss_bwd(const void* pred, const float* target, const float* coef, const float* w, void* dpred,
+                           int b, int64_t E, int dtype, void* stream);
+size_t theia_distill_loss_workspace_bytes(int b, int64_t E);
+
+/* ------------------------------------------------------------------------------------------------
+ * K15: token selection / pooling (models/utils.py:31-43).  x: [b, n, D]; mode 0: x[:, 1:n-disc] -> [b, n-1-disc, D];
+ * 1: mean over those tokens -> [b, D]; 2: max -> [b, D]; 3: cls x[:,0] -> [b, D].  Output is f32.
+ * ---------------------------------------------------------------------------------------------- */
+int theia_token_select(const void* x, float* out, int b, int n, int D, int disc, int mode, int dtype, void* stream);
+
+/* K14: bf16 teacher-feature normalisation with the reference's two bf16 roundings
+ * (dataset/data_utils.py:342-355,374-379): x bf16 [rows, C] -> f32 [rows, C] */
+int theia_feature_norm_bf16(const uint16_t* x, const float* mean, const float* std, float* out, int64_t rows,
+                            int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * elementwise helpers on `dtype` buffers
+ * ---------------------------------------------------------------------------------------------- */
+int theia_add_inplace(void* dst, const void* src, int64_t n, int dtype, void* stream); /* dst += src */
+int theia_fill_zero(void* dst, int64_t bytes, void* stream);
+/* strided copy/accumulate of token rows: dst[b, t0 + t, :] (+)= src[b, t, :] ; used for d(final LN output) */
+int theia_scatter_tokens(const void* src, void* dst, int b, int nsrc, int ndst, int t0, int D, int accumulate,
+                         int dtype, void* stream);
+
+/* fused multi-tensor AdamW over a flat f32 parameter arena (train_rvfm.py:131; torch.optim.AdamW semantics):
+ * p -= lr*(m_hat/(sqrt(v_hat)+eps) + wd*p) with decoupled weight decay; segments give per-range wd. */
+int theia_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, float bias_c1, float bias_c2, float grad_scale, void* stream);
+
+/* hardware probe used by tests: transposed LDS read semantics of ds_read_b64_tr_b16 (out: 64 lanes x 4 u16) */
+int theia_probe_tr16(const uint16_t* lds_image_1024, const int32_t* lane_byte_addr_64, uint16_t* out_256,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THEIA_HIP_H_ */

@@ -1,0 +1,119 @@
+// Shared device/host helpers for the theia_hip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/theia_hip.h"
+
+// ----------------------------------------------------------------------------------
+// error plumbing: every C-ABI entry returns 0 or a negative code; message is thread-local
+// ----------------------------------------------------------------------------------
+void theia_set_error(const char* fmt, ...);
+
+#define THEIA_CHECK_ARG(cond, ...)                 \
+    do {                                           \
+        if (!(cond)) {                             \
+            theia_set_error(__VA_ARGS__);          \
+            return THEIA_ERR_INVALID;              \
+        }                                          \
+    } while (0)
+
+#define THEIA_CHECK_LAUNCH(name)                                                   \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            theia_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return THEIA_ERR_LAUNCH;                                               \
+        }                                                                          \
+    } while (0)
+
+// ----------------------------------------------------------------------------------
+// element types.  bf16 is carried as uint16_t bit patterns; conversions are explicit RNE.
+// ----------------------------------------------------------------------------------
+typedef uint16_t bf16_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                          // round-nearest-even
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kPer16B = 4;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int kPer16B = 8;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 8 consecutive elements <-> 8 floats (vector global access: 16 B for bf16, 2x16 B for f32)
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ----------------------------------------------------------------------------------
+// wave64 / block reductions
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x == NT (multiple of 64); `red` is NT/64 floats of LDS. All threads get the sum.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) s += red[i];
+    return s;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+static inline int cdiv_i(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,559 @@
+// MFMA GEMM kernels of the Theia hot path (gfx950 / CDNA4).
+//
+//   gemm_nt_kernel    out[m,n] = epi( sum_k A[m,k] W[n,k] )    A gathered through a theia_rowmap_t (implicit
+//                     GEMM for Linear / Conv3x3 / ConvTranspose3x3 and every data-gradient)
+//   gemm_wgrad_kernel slab[s][n][k] = sum_{m in split s} dY[m,n] A[m,k]   (weight gradients, split over M)
+//
+// Tiling: 256 threads = 4 wave64; LDS tiles are [rows][128 B] (64 bf16 / 32 f32 of K per row) with the 16-byte
+// chunk index XOR-swizzled by (row>>1)&7 so every ds_read_b128 fragment read is bank-conflict free; operands are
+// staged global -> registers -> LDS with the next tile's loads issued before the current tile's MFMAs.
+// bf16: v_mfma_f32_16x16x32_bf16 (one 16-byte chunk per lane = 8 consecutive k).
+// f32 : v_mfma_f32_16x16x4_f32, four per chunk (k order inside a tile is permuted identically for both operands,
+//       which leaves the sum unchanged up to fp32 association).
+// The MFMA is issued with the WEIGHT fragment as its A operand and the ACTIVATION fragment as its B operand, so a
+// lane ends up with 4 consecutive n for one m: the accumulator tile goes to LDS with ds_write_b128 and is re-read
+// row-contiguously, giving a fully vectorised epilogue (16-byte bias/residual/aux loads and output stores).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
+typedef __attribute__((ext_vector_type(4))) float f32x4_v;
+typedef __attribute__((ext_vector_type(4))) short s16x4_v;
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    __device__ static __forceinline__ void run(f32x4_v& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_v, a), __builtin_bit_cast(bf16x8_v, b),
+                                                      acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    __device__ static __forceinline__ void run(f32x4_v& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+// XCD-aware bijective block remap: hardware places block b on XCD b % 8; give each XCD a contiguous range of tiles
+// so that neighbouring tiles (which share operand panels) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// ================================================================================================
+// NT implicit GEMM
+// ================================================================================================
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const theia_gemm_args_t p) {
+    constexpr int KT = 128 / (int)sizeof(T);   // k elements per LDS row
+    constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int NPA = BM / 32, NPB = BN / 32;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int EP_PITCH = WN + 4;  // floats
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const theia_rowmap_t& mp = p.map;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.a);
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.w);
+
+    // ---- per-thread staging rows (fixed for the whole K loop) ----
+    const int st_chunk = tid & 7, st_row = tid >> 3;
+    const int R = mp.rows_h * mp.rows_w;
+    int64_t a_base[NPA];
+    int a_iy0[NPA], a_ix0[NPA];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int m = m0 + st_row + 32 * i;
+        if (m < p.M) {
+            const int img = m / R, rem = m - img * R;
+            const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
+            a_base[i] = (int64_t)img * mp.in_batch_stride + mp.in_offset;
+            a_iy0[i] = ry * mp.in_sy;
+            a_ix0[i] = rx * mp.in_sx;
+        } else {
+            a_base[i] = 0;
+            a_iy0[i] = -(1 << 28);
+            a_ix0[i] = 0;
+        }
+    }
+    int64_t w_base[NPB];
+    bool w_ok[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int n = n0 + st_row + 32 * i;
+        w_ok[i] = n < p.N;
+        w_base[i] = (int64_t)n * p.ldw;
+    }
+
+    uint4 ra[NPA], rb[NPB];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * KT;
+        const int tap = k0 / mp.in_c;
+        const int c = k0 - tap * mp.in_c + st_chunk * EPC;
+        const bool cok = c < mp.in_c;
+        const int dy = mp.dy[tap], dx = mp.dx[tap];
+        const int64_t wcol = (int64_t)mp.wslot[tap] * mp.in_c + c;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+            const bool ok = cok && iy >= 0 && iy < mp.in_h && ix >= 0 && ix < mp.in_w;
+            ra[i] = make_uint4(0, 0, 0, 0);
+            if (ok) ra[i] = *reinterpret_cast<const uint4*>(A + a_base[i] + (int64_t)(iy * mp.in_w + ix) * mp.in_c + c);
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            rb[i] = make_uint4(0, 0, 0, 0);
+            if (cok && w_ok[i]) rb[i] = *reinterpret_cast<const uint4*>(W + w_base[i] + wcol);
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* sa = smem + stage * STAGE;
+        char* sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) *reinterpret_cast<uint4*>(sa + swz_off(st_row + 32 * i, st_chunk)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) *reinterpret_cast<uint4*>(sb + swz_off(st_row + 32 * i, st_chunk)) = rb[i];
+    };
+
+    f32x4_v acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_v){0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (p.K + KT - 1) / KT;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int frow = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const char* sa = smem + cur * STAGE;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 fa[FM], fb[FN];
+#pragma unroll
+            for (int j = 0; j < FM; ++j) fa[j] = *reinterpret_cast<const uint4*>(sa + swz_off(wm * WM + j * 16 + frow, kk * 4 + fg));
+#pragma unroll
+            for (int i = 0; i < FN; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz_off(wn * WN + i * 16 + frow, kk * 4 + fg));
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) Mma<T>::run(acc[i][j], fb[i], fa[j]);
+        }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> per-wave LDS tile [WM][WN+4] f32 -> row-contiguous vector epilogue ----
+    float* ep = reinterpret_cast<float*>(smem) + wave * (WM * EP_PITCH);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            float* q = ep + (j * 16 + frow) * EP_PITCH + i * 16 + fg * 4;
+            *reinterpret_cast<float4*>(q) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own-wave LDS writes done (wave-private region)
+    __builtin_amdgcn_wave_barrier();
+
+    constexpr int LPR = WN / 8;        // lanes per row
+    constexpr int RPP = 64 / LPR;      // rows per pass
+    T* __restrict__ O = reinterpret_cast<T*>(p.out);
+    const T* __restrict__ RES = reinterpret_cast<const T*>(p.resid);
+    const T* __restrict__ AUXI = reinterpret_cast<const T*>(p.aux_in);
+    T* __restrict__ AUXO = reinterpret_cast<T*>(p.aux_out);
+    const int col = (lane % LPR) * 8;
+    const int n = n0 + wn * WN + col;
+    float bias8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bias8[j] = 0.f;
+    if (p.bias != nullptr && n < p.N) load8(p.bias + n, bias8);
+#pragma unroll
+    for (int ps = 0; ps < WM / RPP; ++ps) {
+        const int row = ps * RPP + lane / LPR;
+        const int m = m0 + wm * WM + row;
+        if (m >= p.M || n >= p.N) continue;
+        float v[8];
+        load8(ep + row * EP_PITCH + col, v);
+        const int img = m / R, rem = m - img * R;
+        const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
+        const int64_t o = (int64_t)img * mp.out_batch_stride + mp.out_offset +
+                          (int64_t)((ry * mp.out_sy + mp.out_y0) * mp.out_w + rx * mp.out_sx + mp.out_x0) * p.ldo + n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += bias8[j];
+        if (p.rowtab != nullptr) {
+            float t8[8];
+            load8(p.rowtab + (int64_t)(m % p.rowtab_period) * p.N + n, t8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += t8[j];
+        }
+        if (p.act == THEIA_ACT_GELU) {
+            if (AUXO != nullptr) store8(AUXO + o, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+        } else if (p.act == THEIA_ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        } else if (p.act == THEIA_ACT_MUL_DGELU) {
+            float a8[8];
+            load8(AUXI + o, a8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= gelu_erf_grad(a8[j]);
+        } else if (p.act == THEIA_ACT_MUL_DRELU) {
+            float a8[8];
+            load8(AUXI + o, a8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = a8[j] > 0.f ? v[j] : 0.f;
+        }
+        if (RES != nullptr) {
+            float r8[8];
+            load8(RES + o, r8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += r8[j];
+        }
+        store8(O + o, v);
+    }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_gemm_nt(const theia_gemm_args_t* a, hipStream_t stream) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int stage_bytes = 2 * (BM + BN) * 128;
+    constexpr int ep_bytes = 4 * WM * (WN + 4) * 4;
+    constexpr int lds = stage_bytes > ep_bytes ? stage_bytes : ep_bytes;
+    auto kern = gemm_nt_kernel<T, BM, BN, WAVES_M, WAVES_N>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int tiles = cdiv_i(a->M, BM) * cdiv_i(a->N, BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, stream, *a);
+    THEIA_CHECK_LAUNCH("theia_gemm_nt");
+    return THEIA_OK;
+}
+
+static int check_rowmap(const theia_rowmap_t& m, int kt, const char* who) {
+    THEIA_CHECK_ARG(m.ntaps >= 1 && m.ntaps <= THEIA_MAX_TAPS, "%s: ntaps=%d out of range", who, m.ntaps);
+    THEIA_CHECK_ARG(m.rows_h >= 1 && m.rows_w >= 1 && m.in_h >= 1 && m.in_w >= 1 && m.out_w >= 1, "%s: bad row map grid", who);
+    THEIA_CHECK_ARG(m.in_c >= 1, "%s: in_c=%d", who, m.in_c);
+    THEIA_CHECK_ARG(m.ntaps == 1 || m.in_c % kt == 0, "%s: in_c=%d must be a multiple of %d for a multi-tap gather", who, m.in_c, kt);
+    return THEIA_OK;
+}
+
+extern "C" int theia_gemm_nt(const theia_gemm_args_t* a, int dtype, void* stream) {
+    THEIA_CHECK_ARG(a != nullptr, "theia_gemm_nt: null args");
+    THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16, "theia_gemm_nt: bad dtype %d", dtype);
+    THEIA_CHECK_ARG(a->a && a->w && a->out, "theia_gemm_nt: null operand pointer");
+    THEIA_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "theia_gemm_nt: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
+    const int epc = dtype == THEIA_BF16 ? 8 : 4;
+    THEIA_CHECK_ARG(a->N % 8 == 0, "theia_gemm_nt: N=%d must be a multiple of 8", a->N);
+    THEIA_CHECK_ARG(a->K % epc == 0 && a->ldw % epc == 0, "theia_gemm_nt: K=%d / ldw=%d must be multiples of %d", a->K, a->ldw, epc);
+    THEIA_CHECK_ARG(a->K == a->map.ntaps * a->map.in_c, "theia_gemm_nt: K=%d != ntaps*in_c=%d", a->K, a->map.ntaps * a->map.in_c);
+    THEIA_CHECK_ARG(a->ldo % 8 == 0 && a->map.out_offset % 8 == 0 && a->map.out_batch_stride % 8 == 0,
+                    "theia_gemm_nt: output pitch/offset must be multiples of 8 elements");
+    THEIA_CHECK_ARG(a->map.in_c % epc == 0 && a->map.in_offset % epc == 0 && a->map.in_batch_stride % epc == 0,
+                    "theia_gemm_nt: input pitch/offset must be multiples of %d elements", epc);
+    THEIA_CHECK_ARG(a->act >= 0 && a->act <= THEIA_ACT_MUL_DRELU, "theia_gemm_nt: bad act %d", a->act);
+    THEIA_CHECK_ARG((a->act != THEIA_ACT_MUL_DGELU && a->act != THEIA_ACT_MUL_DRELU) || a->aux_in, "theia_gemm_nt: act needs aux_in");
+    THEIA_CHECK_ARG(a->rowtab == nullptr || a->rowtab_period > 0, "theia_gemm_nt: rowtab_period");
+    int rc = check_rowmap(a->map, dtype == THEIA_BF16 ? 64 : 32, "theia_gemm_nt");
+    if (rc) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // narrow tile when a 128-wide N tile would waste > 12 % of the MFMA work
+    const int t128 = cdiv_i(a->N, 128) * 128;
+    const bool narrow = (t128 - a->N) * 8 > t128;
+    if (dtype == THEIA_BF16) {
+        return narrow ? launch_gemm_nt<bf16_t, 128, 64, 2, 2>(a, s) : launch_gemm_nt<bf16_t, 128, 128, 2, 2>(a, s);
+    }
+    return narrow ? launch_gemm_nt<float, 128, 64, 2, 2>(a, s) : launch_gemm_nt<float, 128, 128, 2, 2>(a, s);
+}
+
+// ================================================================================================
+// weight-gradient GEMM (reduction over rows m; both operands are m-major so fragments need a transpose)
+// ================================================================================================
+template <typename T> struct WgTile;
+template <> struct WgTile<bf16_t> {
+    static constexpr int MS = 64;          // rows (m) per step
+    static constexpr int PAD = 32;         // bytes of row padding
+};
+template <> struct WgTile<float> {
+    static constexpr int MS = 32;
+    static constexpr int PAD = 64;
+};
+
+// BNN: n tile (dY columns), BC: c tile (A columns inside one tap)
+template <typename T, int BNN, int BC>
+__global__ __launch_bounds__(256) void gemm_wgrad_kernel(const theia_wgrad_args_t p) {
+    constexpr int MS = WgTile<T>::MS;
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int PY = BNN * (int)sizeof(T) + WgTile<T>::PAD;  // dY tile row pitch (bytes)
+    constexpr int PX = BC * (int)sizeof(T) + WgTile<T>::PAD;   // A  tile row pitch
+    constexpr int CY = BNN / EPC, CX = BC / EPC;               // chunks per row
+    constexpr int NCY = MS * CY / 256, NCX = MS * CX / 256;    // chunks per thread
+    constexpr int STAGE = MS * (PY + PX);
+    constexpr int WNN = BNN / 2, WCC = BC / 2;                 // per-wave sub-tile (2 x 2 waves)
+    constexpr int FNn = WNN / 16, FC = WCC / 16;
+    static_assert(NCY >= 1 && NCX >= 1, "tile too small");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wnn = wave >> 1, wcc = wave & 1;
+    const theia_rowmap_t& mp = p.map;
+    const int tiles_n = (p.N + BNN - 1) / BNN;
+    const int tiles_c_per_tap = mp.in_c / BC;
+    const int tiles_k = mp.ntaps * tiles_c_per_tap;
+    const int ntile = tiles_n * tiles_k;
+    const int tile = blockIdx.x % ntile, split = blockIdx.x / ntile;
+    const int tn = tile % tiles_n, tk = tile / tiles_n;
+    const int tap = tk / tiles_c_per_tap, c0 = (tk - tap * tiles_c_per_tap) * BC;
+    const int n0 = tn * BNN;
+    const int dy = mp.dy[tap], dx = mp.dx[tap];
+
+    const int nsteps = (p.M + MS - 1) / MS;
+    const int per = (nsteps + p.splits - 1) / p.splits;
+    const int s_begin = split * per, s_end = min(nsteps, s_begin + per);
+
+    const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.a);
+    const int R = mp.rows_h * mp.rows_w;
+
+    uint4 ry_[NCY], rx_[NCX];
+    auto load_step = [&](int s) {
+        const int mbase = s * MS;
+#pragma unroll
+        for (int i = 0; i < NCY; ++i) {
+            const int id = tid + i * 256;
+            const int row = id / CY, ch = id - row * CY;
+            const int m = mbase + row;
+            const int n = n0 + ch * EPC;
+            ry_[i] = make_uint4(0, 0, 0, 0);
+            if (m < p.M && n < p.N) {
+                const int img = m / R, rem = m - img * R;
+                const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
+                const int64_t o = (int64_t)img * mp.out_batch_stride + mp.out_offset +
+                                  (int64_t)((ry * mp.out_sy + mp.out_y0) * mp.out_w + rx * mp.out_sx + mp.out_x0) * p.ldo + n;
+                ry_[i] = *reinterpret_cast<const uint4*>(DY + o);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NCX; ++i) {
+            const int id = tid + i * 256;
+            const int row = id / CX, ch = id - row * CX;
+            const int m = mbase + row;
+            rx_[i] = make_uint4(0, 0, 0, 0);
+            if (m < p.M) {
+                const int img = m / R, rem = m - img * R;
+                const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
+                const int iy = ry * mp.in_sy + dy, ix = rx * mp.in_sx + dx;
+                if (iy >= 0 && iy < mp.in_h && ix >= 0 && ix < mp.in_w) {
+                    const int64_t o = (int64_t)img * mp.in_batch_stride + mp.in_offset + (int64_t)(iy * mp.in_w + ix) * mp.in_c + c0 + ch * EPC;
+                    rx_[i] = *reinterpret_cast<const uint4*>(A + o);
+                }
+            }
+        }
+    };
+    auto store_step = [&](int stage) {
+        char* sy = smem + stage * STAGE;
+        char* sx = sy + MS * PY;
+#pragma unroll
+        for (int i = 0; i < NCY; ++i) {
+            const int id = tid + i * 256;
+            const int row = id / CY, ch = id - row * CY;
+            *reinterpret_cast<uint4*>(sy + row * PY + ch * 16) = ry_[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NCX; ++i) {
+            const int id = tid + i * 256;
+            const int row = id / CX, ch = id - row * CX;
+            *reinterpret_cast<uint4*>(sx + row * PX + ch * 16) = rx_[i];
+        }
+    };
+
+    // D[i = c][j = n]: MFMA A operand = activation (rows c), B operand = dY (cols n)
+    f32x4_v acc[FC][FNn];
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+        for (int j = 0; j < FNn; ++j) acc[i][j] = (f32x4_v){0.f, 0.f, 0.f, 0.f};
+
+    if (s_begin < s_end) {
+        load_step(s_begin);
+        store_step(0);
+    }
+    __syncthreads();
+    const int q = lane & 15, g = lane >> 4;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int cur = (s - s_begin) & 1;
+        if (s + 1 < s_end) load_step(s + 1);
+        const char* sy = smem + cur * STAGE;
+        const char* sx = sy + MS * PY;
+        if constexpr (sizeof(T) == 2) {
+            // k-slot (g, j<4) <-> row g*4 + j ; (g, j>=4) <-> row 16 + g*4 + (j-4): a half-wave's 8 rows are contiguous
+            // ds_read_b64_tr_b16: lanes 4r..4r+3 of a 16-lane group supply row r (4 x 8 B), lane i receives column i.
+            const int tcol = (q & 3) * 4;
+#pragma unroll
+            for (int ks = 0; ks < MS / 32; ++ks) {
+                const int trow = ks * 32 + g * 4 + (q >> 2);
+                uint4 fx[FC], fy[FNn];
+#pragma unroll
+                for (int i = 0; i < FC; ++i) {
+                    const char* b0 = sx + trow * PX + (wcc * WCC + i * 16 + tcol) * 2;
+                    s16x4_v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_v*)(b0));
+                    s16x4_v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_v*)(b0 + 16 * PX));
+                    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    fx[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                }
+#pragma unroll
+                for (int j = 0; j < FNn; ++j) {
+                    const char* b0 = sy + trow * PY + (wnn * WNN + j * 16 + tcol) * 2;
+                    s16x4_v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_v*)(b0));
+                    s16x4_v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_v*)(b0 + 16 * PY));
+                    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    fy[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                }
+#pragma unroll
+                for (int i = 0; i < FC; ++i)
+#pragma unroll
+                    for (int j = 0; j < FNn; ++j) Mma<bf16_t>::run(acc[i][j], fx[i], fy[j]);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < MS / 4; ++ks) {
+                float fx[FC], fy[FNn];
+                const int row = ks * 4 + g;
+#pragma unroll
+                for (int i = 0; i < FC; ++i) fx[i] = *reinterpret_cast<const float*>(sx + row * PX + (wcc * WCC + i * 16 + q) * 4);
+#pragma unroll
+                for (int j = 0; j < FNn; ++j) fy[j] = *reinterpret_cast<const float*>(sy + row * PY + (wnn * WNN + j * 16 + q) * 4);
+#pragma unroll
+                for (int i = 0; i < FC; ++i)
+#pragma unroll
+                    for (int j = 0; j < FNn; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[i], fy[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (s + 1 < s_end) store_step(cur ^ 1);
+        __syncthreads();
+    }
+
+    // lane holds n = q (+16 j), c = g*4 + r (+16 i): 4 consecutive k of one slab row -> float4 store
+    const int64_t krow = (int64_t)p.kslots * mp.in_c;
+    float* slab = p.slabs + (int64_t)split * p.N * krow;
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+        for (int j = 0; j < FNn; ++j) {
+            const int n = n0 + wnn * WNN + j * 16 + q;
+            const int c = c0 + wcc * WCC + i * 16 + g * 4;
+            if (n < p.N) {
+                float* dst = slab + (int64_t)n * krow + (int64_t)mp.wslot[tap] * mp.in_c + c;
+                *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+}
+
+template <typename T, int BNN, int BC>
+static int launch_wgrad(const theia_wgrad_args_t* a, hipStream_t stream) {
+    constexpr int MS = WgTile<T>::MS;
+    constexpr int PY = BNN * (int)sizeof(T) + WgTile<T>::PAD, PX = BC * (int)sizeof(T) + WgTile<T>::PAD;
+    constexpr int lds = 2 * MS * (PY + PX);
+    auto kern = gemm_wgrad_kernel<T, BNN, BC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int tiles = cdiv_i(a->N, BNN) * a->map.ntaps * (a->map.in_c / BC);
+    hipLaunchKernelGGL(kern, dim3(tiles * a->splits), dim3(256), lds, stream, *a);
+    THEIA_CHECK_LAUNCH("theia_gemm_wgrad");
+    return THEIA_OK;
+}
+
+extern "C" int theia_wgrad_splits(int M, int N, int Ktot) {
+    const int tiles = cdiv_i(N, 128) * cdiv_i(Ktot, 128);
+    const int nsteps = cdiv_i(M, 64);
+    int s = cdiv_i(768, tiles > 0 ? tiles : 1);
+    const int smax = nsteps / 8 > 1 ? nsteps / 8 : 1;
+    if (s > smax) s = smax;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return s;
+}
+
+extern "C" int theia_gemm_wgrad(const theia_wgrad_args_t* a, int dtype, void* stream) {
+    THEIA_CHECK_ARG(a != nullptr, "theia_gemm_wgrad: null args");
+    THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16, "theia_gemm_wgrad: bad dtype %d", dtype);
+    THEIA_CHECK_ARG(a->dy && a->a && a->slabs, "theia_gemm_wgrad: null pointer");
+    THEIA_CHECK_ARG(a->M > 0 && a->N > 0 && a->splits >= 1, "theia_gemm_wgrad: bad shape");
+    THEIA_CHECK_ARG(a->N % 8 == 0, "theia_gemm_wgrad: N=%d must be a multiple of 8", a->N);
+    THEIA_CHECK_ARG(a->map.in_c % 64 == 0, "theia_gemm_wgrad: in_c=%d must be a multiple of 64", a->map.in_c);
+    THEIA_CHECK_ARG(a->ldo % 8 == 0 && a->map.out_offset % 8 == 0 && a->map.out_batch_stride % 8 == 0 &&
+                        a->map.in_offset % 8 == 0 && a->map.in_batch_stride % 8 == 0,
+                    "theia_gemm_wgrad: pitches/offsets must be multiples of 8 elements");
+    for (int t = 0; t < a->map.ntaps; ++t)
+        THEIA_CHECK_ARG(a->map.wslot[t] >= 0 && a->map.wslot[t] < a->kslots, "theia_gemm_wgrad: wslot out of range");
+    int rc = check_rowmap(a->map, 64, "theia_gemm_wgrad");
+    if (rc) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool n128 = a->N % 128 == 0, c128 = a->map.in_c % 128 == 0;
+    if (dtype == THEIA_BF16) {
+        if (n128 && c128) return launch_wgrad<bf16_t, 128, 128>(a, s);
+        if (n128) return launch_wgrad<bf16_t, 128, 64>(a, s);
+        if (c128) return launch_wgrad<bf16_t, 64, 128>(a, s);
+        return launch_wgrad<bf16_t, 64, 64>(a, s);
+    }
+    if (n128 && c128) return launch_wgrad<float, 128, 128>(a, s);
+    if (n128) return launch_wgrad<float, 128, 64>(a, s);
+    if (c128) return launch_wgrad<float, 64, 128>(a, s);
+    return launch_wgrad<float, 64, 64>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// slab reduction + permutation into the reference parameter layout
+// ------------------------------------------------------------------------------------------------
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, int N, int kslots, int C,
+                                    float* __restrict__ out, int64_t sn, int64_t ss, int64_t sc, int accumulate) {
+    const int64_t krow = (int64_t)kslots * C;
+    const int64_t total = (int64_t)N * krow;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slabs[(int64_t)k * total + i];
+        const int n = (int)(i / krow);
+        const int r = (int)(i - (int64_t)n * krow);
+        const int slot = r / C, ci = r - slot * C;
+        const int64_t o = n * sn + slot * ss + ci * sc;
+        out[o] = accumulate ? out[o] + s : s;
+    }
+}
+
+extern "C" int theia_wgrad_reduce(const float* slabs, int splits, int N, int kslots, int C, float* out, int64_t sn,
+                                  int64_t ss, int64_t sc, int accumulate, void* stream) {
+    THEIA_CHECK_ARG(slabs && out && splits >= 1 && N > 0 && kslots > 0 && C > 0, "theia_wgrad_reduce: bad args");
+    const int64_t total = (int64_t)N * kslots * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), slabs,
+                       splits, N, kslots, C, out, sn, ss, sc, accumulate);
+    THEIA_CHECK_LAUNCH("theia_wgrad_reduce");
+    return THEIA_OK;
+}

@@ -1,0 +1,558 @@
+// HBM-bound helper kernels of the Theia hot path: parameter casts/permutes, image ingest, distillation loss,
+// token selection, bias-gradient column sums, fused AdamW, and a hardware probe for ds_read_b64_tr_b16.
+#include <stdarg.h>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void theia_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* theia_last_error(void) { return g_err; }
+extern "C" int theia_abi_version(void) { return THEIA_ABI_VERSION; }
+extern "C" int theia_dtype_size(int dtype) { return dtype == THEIA_F32 ? 4 : dtype == THEIA_BF16 ? 2 : -1; }
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32, who)                 \
+    if ((dtype) == THEIA_BF16) {                                    \
+        CALL_BF16;                                                  \
+    } else if ((dtype) == THEIA_F32) {                              \
+        CALL_F32;                                                   \
+    } else {                                                        \
+        THEIA_CHECK_ARG(false, "%s: bad dtype %d", who, (int)dtype); \
+    }
+
+static inline int grid_for(int64_t n, int per_block, int cap = 65535 * 4) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// casts / permutes
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        Elem<T>::st(dst + i, src[i]);
+}
+extern "C" int theia_cast(const float* src, void* dst, int64_t n, int dtype, void* stream) {
+    THEIA_CHECK_ARG(src && dst && n > 0, "theia_cast: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int g = grid_for(n, 256, 8192);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(g), dim3(256), 0, s, src, (bf16_t*)dst, n),
+               hipLaunchKernelGGL(cast_kernel<float>, dim3(g), dim3(256), 0, s, src, (float*)dst, n), "theia_cast");
+    THEIA_CHECK_LAUNCH("theia_cast");
+    return THEIA_OK;
+}
+
+template <typename T>
+__global__ void cast_transpose_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int C, int64_t ldd) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < R && c < C) ? src[(int64_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (r < R && c < C) Elem<T>::st(dst + (int64_t)c * ldd + r, tile[threadIdx.x][i]);
+    }
+}
+extern "C" int theia_cast_transpose(const float* src, void* dst, int R, int C, int64_t ldd, int dtype, void* stream) {
+    THEIA_CHECK_ARG(src && dst && R > 0 && C > 0 && ldd >= R, "theia_cast_transpose: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((C + 31) / 32, (R + 31) / 32), blk(32, 8);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, grid, blk, 0, s, src, (bf16_t*)dst, R, C, ldd),
+               hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, blk, 0, s, src, (float*)dst, R, C, ldd), "theia_cast_transpose");
+    THEIA_CHECK_LAUNCH("theia_cast_transpose");
+    return THEIA_OK;
+}
+
+template <typename T>
+__global__ void cast_permute3_kernel(const float* __restrict__ src, T* __restrict__ dst, int d0, int d1, int d2,
+                                     int64_t s0, int64_t s1, int64_t s2) {
+    const int64_t n = (int64_t)d0 * d1 * d2;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(o % d2);
+        const int64_t ij = o / d2;
+        const int j = (int)(ij % d1), i = (int)(ij / d1);
+        Elem<T>::st(dst + o, src[i * s0 + j * s1 + k * s2]);
+    }
+}
+extern "C" int theia_cast_permute3(const float* src, void* dst, int d0, int d1, int d2, int64_t s0, int64_t s1,
+                                   int64_t s2, int dtype, void* stream) {
+    THEIA_CHECK_ARG(src && dst && d0 > 0 && d1 > 0 && d2 > 0, "theia_cast_permute3: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int g = grid_for((int64_t)d0 * d1 * d2, 256, 8192);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(cast_permute3_kernel<bf16_t>, dim3(g), dim3(256), 0, s, src, (bf16_t*)dst, d0, d1, d2, s0, s1, s2),
+               hipLaunchKernelGGL(cast_permute3_kernel<float>, dim3(g), dim3(256), 0, s, src, (float*)dst, d0, d1, d2, s0, s1, s2),
+               "theia_cast_permute3");
+    THEIA_CHECK_LAUNCH("theia_cast_permute3");
+    return THEIA_OK;
+}
+
+__global__ void unpermute3_kernel(const float* __restrict__ src, float* __restrict__ dst, int d0, int d1, int d2,
+                                  int64_t t0, int64_t t1, int64_t t2, int accumulate) {
+    const int64_t n = (int64_t)d0 * d1 * d2;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(o % d2);
+        const int64_t ij = o / d2;
+        const int j = (int)(ij % d1), i = (int)(ij / d1);
+        const int64_t d = i * t0 + j * t1 + k * t2;
+        dst[d] = accumulate ? dst[d] + src[o] : src[o];
+    }
+}
+extern "C" int theia_unpermute3_f32(const float* src, float* dst, int d0, int d1, int d2, int64_t t0, int64_t t1,
+                                    int64_t t2, int accumulate, void* stream) {
+    THEIA_CHECK_ARG(src && dst && d0 > 0 && d1 > 0 && d2 > 0, "theia_unpermute3_f32: bad args");
+    const int g = grid_for((int64_t)d0 * d1 * d2, 256, 8192);
+    hipLaunchKernelGGL(unpermute3_kernel, dim3(g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, d0, d1, d2, t0, t1, t2, accumulate);
+    THEIA_CHECK_LAUNCH("theia_unpermute3_f32");
+    return THEIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: uint8 image -> normalised patch matrix.  One thread produces 8 consecutive kx of one (patch, c, ky).
+// Token/patch indexing is integer-exact: row = b*196 + py*14 + px, col = c*256 + ky*16 + kx.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const uint8_t* __restrict__ img, const float* __restrict__ lut,
+                                                       T* __restrict__ out, int b, int channels_last) {
+    __shared__ float slut[768];
+    for (int i = threadIdx.x; i < 768; i += 256) slut[i] = lut[i];
+    __syncthreads();
+    const int64_t nvec = (int64_t)b * 196 * 96;  // 768/8 vectors per row
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(v % 96);
+        const int64_t row = v / 96;
+        const int p = (int)(row % 196), bi = (int)(row / 196);
+        const int py = p / 14, px = p - py * 14;
+        const int k = cv * 8;
+        const int c = k >> 8, ky = (k >> 4) & 15, kx = k & 15;
+        const int y = py * 16 + ky, x = px * 16 + kx;
+        float o[8];
+        if (channels_last) {
+            const uint8_t* src = img + (((int64_t)bi * 224 + y) * 224 + x) * 3 + c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = slut[c * 256 + src[3 * j]];
+        } else {
+            const uint8_t* src = img + (((int64_t)bi * 3 + c) * 224 + y) * 224 + x;
+            const uint2 w = *reinterpret_cast<const uint2*>(src);  // 8-byte aligned: x % 8 == 0
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = slut[c * 256 + ((w.x >> (8 * j)) & 0xff)];
+                o[4 + j] = slut[c * 256 + ((w.y >> (8 * j)) & 0xff)];
+            }
+        }
+        store8(out + row * 768 + k, o);
+    }
+}
+extern "C" int theia_patchify_u8(const uint8_t* img, const float* lut, void* out, int b, int channels_last, int dtype,
+                                 void* stream) {
+    THEIA_CHECK_ARG(img && lut && out && b > 0, "theia_patchify_u8: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int g = grid_for((int64_t)b * 196 * 96, 256, 16384);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(g), dim3(256), 0, s, img, lut, (bf16_t*)out, b, channels_last),
+               hipLaunchKernelGGL(patchify_kernel<float>, dim3(g), dim3(256), 0, s, img, lut, (float*)out, b, channels_last),
+               "theia_patchify_u8");
+    THEIA_CHECK_LAUNCH("theia_patchify_u8");
+    return THEIA_OK;
+}
+
+template <typename T>
+__global__ void write_cls_kernel(const float* __restrict__ cls, const float* __restrict__ pos, T* __restrict__ h, int b,
+                                 int ntok, int D) {
+    const int64_t n = (int64_t)b * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int64_t bi = i / D;
+        Elem<T>::st(h + bi * ntok * D + d, cls[d] + pos[d]);
+    }
+}
+extern "C" int theia_write_cls(const float* cls, const float* pos, void* h, int b, int ntok, int D, int dtype, void* stream) {
+    THEIA_CHECK_ARG(cls && pos && h && b > 0 && D > 0, "theia_write_cls: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int g = grid_for((int64_t)b * D, 256, 4096);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(write_cls_kernel<bf16_t>, dim3(g), dim3(256), 0, s, cls, pos, (bf16_t*)h, b, ntok, D),
+               hipLaunchKernelGGL(write_cls_kernel<float>, dim3(g), dim3(256), 0, s, cls, pos, (float*)h, b, ntok, D), "theia_write_cls");
+    THEIA_CHECK_LAUNCH("theia_write_cls");
+    return THEIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bias gradient: column sums of a [M, N] matrix.  Block = 64 column-vectors(8) x 4 row lanes; two stages.
+// ------------------------------------------------------------------------------------------------
+constexpr int CS_ROWS = 512;  // rows per block in stage 1
+static int colsum_rowblocks(int64_t M) { return (int)((M + CS_ROWS - 1) / CS_ROWS); }
+extern "C" size_t theia_colsum_workspace_bytes(int64_t M, int N) { return (size_t)colsum_rowblocks(M) * N * sizeof(float); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t M, int N, int64_t ld,
+                                                     float* __restrict__ part) {
+    __shared__ float red[4][64][8];
+    const int cv = blockIdx.x * 64 + (threadIdx.x & 63);  // column vector index
+    const int rl = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    if (cv * 8 < N) {
+        const int64_t r1 = min(M, r0 + CS_ROWS);
+        for (int64_t r = r0 + rl; r < r1; r += 4) {
+            float v[8];
+            load8(x + r * ld + cv * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rl][threadIdx.x & 63][j] = a[j];
+    __syncthreads();
+    if (rl == 0 && cv * 8 < N) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = red[0][threadIdx.x][j] + red[1][threadIdx.x][j] + red[2][threadIdx.x][j] + red[3][threadIdx.x][j];
+        store8(part + (int64_t)blockIdx.y * N + cv * 8, o);
+    }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * N + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+extern "C" int theia_colsum(const void* x, int64_t M, int N, int64_t ld, float* out, float* workspace, int accumulate,
+                            int dtype, void* stream) {
+    THEIA_CHECK_ARG(x && out && workspace && M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0, "theia_colsum: bad args (N, ld multiples of 8)");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int rb = colsum_rowblocks(M);
+    const dim3 grid((N / 8 + 63) / 64, rb);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, M, N, ld, workspace),
+               hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, M, N, ld, workspace), "theia_colsum");
+    THEIA_CHECK_LAUNCH("theia_colsum");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, workspace, rb, N, out, accumulate);
+    THEIA_CHECK_LAUNCH("theia_colsum(final)");
+    return THEIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K13: distillation losses.  Stage 1: per (sample, chunk) partial sums of
+//   d^2, smoothL1(d), p*q, p*p, q*q ;  stage 2: per-teacher scalars + per-sample cosine coefficients.
+// ------------------------------------------------------------------------------------------------
+constexpr int LOSS_CHUNK = 8192;
+static int loss_chunks(int64_t E) { return (int)((E + LOSS_CHUNK - 1) / LOSS_CHUNK); }
+extern "C" size_t theia_distill_loss_workspace_bytes(int b, int64_t E) { return (size_t)b * loss_chunks(E) * 5 * sizeof(float); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void loss_partial_kernel(const T* __restrict__ pred, const float* __restrict__ target,
+                                                           float* __restrict__ part, int64_t E, int nchunks) {
+    __shared__ float red[5][4];
+    const int sample = blockIdx.y, chunk = blockIdx.x;
+    const int64_t base = (int64_t)sample * E;
+    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < LOSS_CHUNK / (256 * 8); ++it) {
+        const int64_t e = (int64_t)chunk * LOSS_CHUNK + (it * 256 + threadIdx.x) * 8;
+        if (e < E) {
+            float p[8], q[8];
+            load8(pred + base + e, p);
+            load8(target + base + e, q);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = p[j] - q[j];
+                const float a = fabsf(d);
+                s[0] += d * d;
+                s[1] += a < 1.0f ? 0.5f * d * d : a - 0.5f;
+                s[2] += p[j] * q[j];
+                s[3] += p[j] * p[j];
+                s[4] += q[j] * q[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float t = block_sum<256>(s[k], red[k]);
+        if (threadIdx.x == 0) part[((int64_t)sample * nchunks + chunk) * 5 + k] = t;
+    }
+}
+
+// one block; thread i handles sample i (strided); follows models/rvfm.py:158-168 including both epsilons
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ part, float* __restrict__ losses,
+                                                            float* __restrict__ coef, int b, int nchunks, int64_t E) {
+    __shared__ double red[3][256];
+    double mse = 0.0, l1 = 0.0, cosl = 0.0;
+    for (int s = threadIdx.x; s < b; s += 256) {
+        double a[5] = {0, 0, 0, 0, 0};
+        for (int c = 0; c < nchunks; ++c)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) a[k] += (double)part[((int64_t)s * nchunks + c) * 5 + k];
+        mse += a[0];
+        l1 += a[1];
+        const double np = fmax(sqrt(a[3]), 1e-12), nq = fmax(sqrt(a[4]), 1e-12);  // F.normalize eps
+        const double dot = a[2] / (np * nq);
+        const double m1 = a[3] / (np * np) + 1e-12, m2 = a[4] / (nq * nq) + 1e-12;  // CosineEmbeddingLoss EPSILON
+        const double c = dot / sqrt(m1 * m2);
+        cosl += 1.0 - c;
+        // d(mean_i(1 - c_i))/dp_i = beta_i * p_i - alpha_i * q_i
+        coef[2 * s] = (float)(1.0 / ((double)b * np * nq));
+        coef[2 * s + 1] = (float)(c / ((double)b * np * np));
+    }
+    red[0][threadIdx.x] = mse;
+    red[1][threadIdx.x] = l1;
+    red[2][threadIdx.x] = cosl;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+            red[2][threadIdx.x] += red[2][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double n = (double)b * (double)E;
+        losses[0] = (float)(red[0][0] / n);
+        losses[1] = (float)(red[2][0] / (double)b);
+        losses[2] = (float)(red[1][0] / n);
+    }
+}
+
+extern "C" int theia_distill_loss_fwd(const void* pred, const float* target, float* losses, float* coef, float* workspace,
+                                      int b, int64_t E, int dtype, void* stream) {
+    THEIA_CHECK_ARG(pred && target && losses && coef && workspace, "theia_distill_loss_fwd: null pointer");
+    THEIA_CHECK_ARG(b > 0 && E > 0 && E % 8 == 0, "theia_distill_loss_fwd: E must be a positive multiple of 8");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nch = loss_chunks(E);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(loss_partial_kernel<bf16_t>, dim3(nch, b), dim3(256), 0, s, (const bf16_t*)pred, target, workspace, E, nch),
+               hipLaunchKernelGGL(loss_partial_kernel<float>, dim3(nch, b), dim3(256), 0, s, (const float*)pred, target, workspace, E, nch),
+               "theia_distill_loss_fwd");
+    THEIA_CHECK_LAUNCH("theia_distill_loss_fwd(partial)");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, workspace, losses, coef, b, nch, E);
+    THEIA_CHECK_LAUNCH("theia_distill_loss_fwd(finalize)");
+    return THEIA_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pred, const float* __restrict__ target,
+                                                       const float* __restrict__ coef, const float* __restrict__ w,
+                                                       T* __restrict__ dpred, int b, int64_t E) {
+    const int sample = blockIdx.y;
+    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (e >= E) return;
+    const float inv_n = 1.0f / ((float)b * (float)E);
+    const float wm = w[0] * 2.0f * inv_n, wc = w[1], wl = w[2] * inv_n;
+    const float alpha = wc * coef[2 * sample], beta = wc * coef[2 * sample + 1];
+    float p[8], q[8], o[8];
+    load8(pred + (int64_t)sample * E + e, p);
+    load8(target + (int64_t)sample * E + e, q);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float d = p[j] - q[j];
+        o[j] = wm * d + wl * fminf(fmaxf(d, -1.0f), 1.0f) + beta * p[j] - alpha * q[j];
+    }
+    store8(dpred + (int64_t)sample * E + e, o);
+}
+extern "C" int theia_distill_loss_bwd(const void* pred, const float* target, const float* coef, const float* w, void* dpred,
+                                      int b, int64_t E, int dtype, void* stream) {
+    THEIA_CHECK_ARG(pred && target && coef && w && dpred && b > 0 && E > 0 && E % 8 == 0, "theia_distill_loss_bwd: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((E / 8 + 255) / 256), b);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(loss_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)pred, target, coef, w, (bf16_t*)dpred, b, E),
+               hipLaunchKernelGGL(loss_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)pred, target, coef, w, (float*)dpred, b, E),
+               "theia_distill_loss_bwd");
+    THEIA_CHECK_LAUNCH("theia_distill_loss_bwd");
+    return THEIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K15: token selection / pooling -> f32
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void token_select_kernel(const T* __restrict__ x, float* __restrict__ out, int b, int n, int D, int disc, int mode) {
+    const int nsel = n - 1 - disc;
+    if (mode == 0) {
+        const int64_t total = (int64_t)b * nsel * D;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const int d = (int)(i % D);
+            const int64_t bt = i / D;
+            const int t = (int)(bt % nsel);
+            const int64_t bi = bt / nsel;
+            out[i] = Elem<T>::ld(x + (bi * n + 1 + t) * D + d);
+        }
+        return;
+    }
+    const int64_t total = (int64_t)b * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int64_t bi = i / D;
+        const T* base = x + bi * n * D + d;
+        if (mode == 3) {
+            out[i] = Elem<T>::ld(base);
+        } else if (mode == 1) {
+            float s = 0.f;
+            for (int t = 1; t <= nsel; ++t) s += Elem<T>::ld(base + (int64_t)t * D);
+            out[i] = s / (float)nsel;
+        } else {
+            float m = -INFINITY;
+            for (int t = 1; t <= nsel; ++t) m = fmaxf(m, Elem<T>::ld(base + (int64_t)t * D));
+            out[i] = m;
+        }
+    }
+}
+extern "C" int theia_token_select(const void* x, float* out, int b, int n, int D, int disc, int mode, int dtype, void* stream) {
+    THEIA_CHECK_ARG(x && out && b > 0 && n > 1 && D > 0 && disc >= 0 && n - 1 - disc > 0 && mode >= 0 && mode <= 3, "theia_token_select: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = mode == 0 ? (int64_t)b * (n - 1 - disc) * D : (int64_t)b * D;
+    const int g = grid_for(total, 256, 16384);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(token_select_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)x, out, b, n, D, disc, mode),
+               hipLaunchKernelGGL(token_select_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, out, b, n, D, disc, mode),
+               "theia_token_select");
+    THEIA_CHECK_LAUNCH("theia_token_select");
+    return THEIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K14: bf16 feature normalisation with two bf16 roundings (sub, then div), output f32
+// ------------------------------------------------------------------------------------------------
+__global__ void feature_norm_kernel(const uint16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ stdv,
+                                    float* __restrict__ out, int64_t rows, int C) {
+    const int64_t n = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float m = bf16_to_f32(f32_to_bf16(mean[c]));  // stats are cast to bf16 first (data_utils.py:374-379)
+        const float s = bf16_to_f32(f32_to_bf16(stdv[c]));
+        const float d = bf16_to_f32(f32_to_bf16(bf16_to_f32(x[i]) - m));
+        out[i] = bf16_to_f32(f32_to_bf16(d / s));
+    }
+}
+extern "C" int theia_feature_norm_bf16(const uint16_t* x, const float* mean, const float* std, float* out, int64_t rows,
+                                       int C, void* stream) {
+    THEIA_CHECK_ARG(x && mean && std && out && rows > 0 && C > 0, "theia_feature_norm_bf16: bad args");
+    hipLaunchKernelGGL(feature_norm_kernel, dim3(grid_for(rows * C, 256, 16384)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, mean, std, out, rows, C);
+    THEIA_CHECK_LAUNCH("theia_feature_norm_bf16");
+    return THEIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise helpers
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void add_inplace_kernel(T* __restrict__ dst, const T* __restrict__ src, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        float a[8], b[8];
+        load8(dst + i * 8, a);
+        load8(src + i * 8, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += b[j];
+        store8(dst + i * 8, a);
+    }
+}
+extern "C" int theia_add_inplace(void* dst, const void* src, int64_t n, int dtype, void* stream) {
+    THEIA_CHECK_ARG(dst && src && n > 0 && n % 8 == 0, "theia_add_inplace: n must be a positive multiple of 8");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int g = grid_for(n / 8, 256, 16384);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(add_inplace_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (bf16_t*)dst, (const bf16_t*)src, n / 8),
+               hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(g), dim3(256), 0, s, (float*)dst, (const float*)src, n / 8), "theia_add_inplace");
+    THEIA_CHECK_LAUNCH("theia_add_inplace");
+    return THEIA_OK;
+}
+
+extern "C" int theia_fill_zero(void* dst, int64_t bytes, void* stream) {
+    THEIA_CHECK_ARG(dst && bytes >= 0, "theia_fill_zero: bad args");
+    if (bytes == 0) return THEIA_OK;
+    hipError_t e = hipMemsetAsync(dst, 0, (size_t)bytes, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        theia_set_error("theia_fill_zero: %s", hipGetErrorString(e));
+        return THEIA_ERR_LAUNCH;
+    }
+    return THEIA_OK;
+}
+
+template <typename T>
+__global__ void scatter_tokens_kernel(const T* __restrict__ src, T* __restrict__ dst, int b, int nsrc, int ndst, int t0, int D,
+                                      int accumulate) {
+    const int dv = D / 8;
+    const int64_t nvec = (int64_t)b * nsrc * dv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % dv);
+        const int64_t bt = i / dv;
+        const int t = (int)(bt % nsrc);
+        const int64_t bi = bt / nsrc;
+        float a[8];
+        load8(src + i * 8, a);
+        T* q = dst + ((bi * ndst + t0 + t) * D) + d * 8;
+        if (accumulate) {
+            float c[8];
+            load8(q, c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += c[j];
+        }
+        store8(q, a);
+    }
+}
+extern "C" int theia_scatter_tokens(const void* src, void* dst, int b, int nsrc, int ndst, int t0, int D, int accumulate,
+                                    int dtype, void* stream) {
+    THEIA_CHECK_ARG(src && dst && b > 0 && nsrc > 0 && t0 >= 0 && t0 + nsrc <= ndst && D % 8 == 0, "theia_scatter_tokens: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int g = grid_for((int64_t)b * nsrc * (D / 8), 256, 16384);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(scatter_tokens_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, b, nsrc, ndst, t0, D, accumulate),
+               hipLaunchKernelGGL(scatter_tokens_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, b, nsrc, ndst, t0, D, accumulate),
+               "theia_scatter_tokens");
+    THEIA_CHECK_LAUNCH("theia_scatter_tokens");
+    return THEIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused AdamW over a flat f32 range (torch.optim.AdamW semantics: decoupled decay applied first)
+// ------------------------------------------------------------------------------------------------
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi;
+    }
+}
+extern "C" int theia_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, float bias_c1, float bias_c2, float grad_scale, void* stream) {
+    THEIA_CHECK_ARG(p && g && m && v && n > 0, "theia_adamw_step: bad args");
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n, lr,
+                       beta1, beta2, eps, weight_decay, bias_c1, bias_c2, grad_scale);
+    THEIA_CHECK_LAUNCH("theia_adamw_step");
+    return THEIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hardware probe: ds_read_b64_tr_b16 with caller-supplied per-lane LDS byte addresses
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short probe_s16x4;
+__global__ void probe_tr16_kernel(const uint16_t* __restrict__ img, const int32_t* __restrict__ addr, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[1024];
+    for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = img[i];
+    __syncthreads();
+    const char* base = reinterpret_cast<const char*>(lds) + addr[threadIdx.x];
+    probe_s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) probe_s16x4*)(base));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = (uint16_t)r[j];
+}
+extern "C" int theia_probe_tr16(const uint16_t* lds_image_1024, const int32_t* lane_byte_addr_64, uint16_t* out_256, void* stream) {
+    THEIA_CHECK_ARG(lds_image_1024 && lane_byte_addr_64 && out_256, "theia_probe_tr16: null pointer");
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), lds_image_1024, lane_byte_addr_64, out_256);
+    THEIA_CHECK_LAUNCH("theia_probe_tr16");
+    return THEIA_OK;
+}

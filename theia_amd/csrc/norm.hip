@@ -1,0 +1,402 @@
+// LayerNorm kernels of the Theia hot path (HBM-bound, wavefront-reduced, 16-byte vector accesses).
+//   row LayerNorm (ViT blocks, eps 1e-12)            transformers modeling_vit.py:261-262,348
+//   whole-sample LayerNorm over (C,H,W) with affine   adapter_heads.py:306,309,312,318,321,324
+#include "common.h"
+
+// ================================================================================================
+// row LayerNorm: one wave64 per row, row held in registers (D <= 2048, D % 8 == 0)
+// ================================================================================================
+constexpr int LN_MAXV = 4;  // 8-element vectors per lane
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_row_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ y,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, int64_t M,
+                                                         int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nv = D >> 3;
+    const float invD = 1.0f / (float)D;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * 4) {
+        const T* xr = x + row * D;
+        float v[LN_MAXV][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int vi = lane + 64 * i;
+            if (vi < nv) {
+                load8(xr + vi * 8, v[i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[i][j];
+            }
+        }
+        const float mu = wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int vi = lane + 64 * i;
+            if (vi < nv) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = v[i][j] - mu;
+                    q += d * d;
+                }
+            }
+        }
+        const float var = wave_sum(q) * invD;
+        const float rs = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int vi = lane + 64 * i;
+            if (vi < nv) {
+                float g8[8], b8[8], o[8];
+                load8(gamma + vi * 8, g8);
+                load8(beta + vi * 8, b8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * g8[j] + b8[j];
+                store8(y + row * D + vi * 8, o);
+            }
+        }
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+}
+
+extern "C" int theia_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                   float* rstd, int64_t M, int D, float eps, int dtype, void* stream) {
+    THEIA_CHECK_ARG(x && gamma && beta && y && mean && rstd, "theia_layernorm_fwd: null pointer");
+    THEIA_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0 && D <= 8 * 64 * LN_MAXV, "theia_layernorm_fwd: unsupported D=%d", D);
+    int blocks = (int)((M + 3) / 4);
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == THEIA_BF16)
+        hipLaunchKernelGGL(ln_row_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
+    else if (dtype == THEIA_F32)
+        hipLaunchKernelGGL(ln_row_fwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps);
+    else
+        THEIA_CHECK_ARG(false, "theia_layernorm_fwd: bad dtype %d", dtype);
+    THEIA_CHECK_LAUNCH("theia_layernorm_fwd");
+    return THEIA_OK;
+}
+
+// backward: dx per row (wave); dgamma/dbeta accumulated per lane over the rows this wave visits, then
+// block-reduced through LDS and written as one partial row per block; a second kernel sums the partials.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_row_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                         T* __restrict__ dx, float* __restrict__ part, int64_t M, int D) {
+    extern __shared__ float red[];  // [4][2*D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = D >> 3;
+    const float invD = 1.0f / (float)D;
+    float ag[LN_MAXV][8], ab[LN_MAXV][8], g8[LN_MAXV][8];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int vi = lane + 64 * i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ag[i][j] = ab[i][j] = g8[i][j] = 0.f;
+        if (vi < nv) load8(gamma + vi * 8, g8[i]);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[LN_MAXV][8], gy[LN_MAXV][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int vi = lane + 64 * i;
+            if (vi < nv) {
+                float xv[8], dv[8];
+                load8(x + row * D + vi * 8, xv);
+                load8(dy + row * D + vi * 8, dv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xh[i][j] = (xv[j] - mu) * rs;
+                    gy[i][j] = dv[j] * g8[i][j];
+                    s1 += gy[i][j];
+                    s2 += gy[i][j] * xh[i][j];
+                    ag[i][j] += dv[j] * xh[i][j];
+                    ab[i][j] += dv[j];
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) * invD, m2 = wave_sum(s2) * invD;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int vi = lane + 64 * i;
+            if (vi < nv) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = rs * (gy[i][j] - m1 - xh[i][j] * m2);
+                if (dres != nullptr) {
+                    float r8[8];
+                    load8(dres + row * D + vi * 8, r8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] += r8[j];
+                }
+                store8(dx + row * D + vi * 8, o);
+            }
+        }
+    }
+    float* mine = red + wave * 2 * D;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int vi = lane + 64 * i;
+        if (vi < nv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                mine[vi * 8 + j] = ag[i][j];
+                mine[D + vi * 8 + j] = ab[i][j];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256)
+        part[(int64_t)blockIdx.x * 2 * D + i] = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
+}
+
+// out[c] (+)= sum_p part[p][c]  for c in [0, ncol); deterministic order
+__global__ void partial_reduce_kernel(const float* __restrict__ part, int nparts, int ncol, int64_t pitch,
+                                      float* __restrict__ out0, float* __restrict__ out1, int split, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * pitch + c];
+    float* dst = c < split ? out0 + c : out1 + (c - split);
+    *dst = accumulate ? *dst + s : s;
+}
+
+static int ln_bwd_blocks(int64_t M) {
+    int64_t b = (M + 3) / 4;
+    if (b > 1024) b = 1024;
+    return (int)b;
+}
+
+extern "C" size_t theia_layernorm_bwd_workspace_bytes(int64_t M, int D) {
+    return (size_t)ln_bwd_blocks(M) * 2 * D * sizeof(float);
+}
+
+extern "C" int theia_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                   const float* rstd, const void* dresid, void* dx, float* dgamma, float* dbeta,
+                                   float* workspace, int64_t M, int D, int accumulate, int dtype, void* stream) {
+    THEIA_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "theia_layernorm_bwd: null pointer");
+    THEIA_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0 && D <= 8 * 64 * LN_MAXV, "theia_layernorm_bwd: unsupported D=%d", D);
+    const int blocks = ln_bwd_blocks(M);
+    const size_t lds = 4 * 2 * D * sizeof(float);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == THEIA_BF16)
+        hipLaunchKernelGGL(ln_row_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dresid, (bf16_t*)dx, workspace, M, D);
+    else if (dtype == THEIA_F32)
+        hipLaunchKernelGGL(ln_row_bwd_kernel<float>, dim3(blocks), dim3(256), lds, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dresid, (float*)dx, workspace, M, D);
+    else
+        THEIA_CHECK_ARG(false, "theia_layernorm_bwd: bad dtype %d", dtype);
+    THEIA_CHECK_LAUNCH("theia_layernorm_bwd");
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, s, workspace, blocks, 2 * D,
+                       (int64_t)2 * D, dgamma, dbeta, D, accumulate);
+    THEIA_CHECK_LAUNCH("theia_layernorm_bwd(reduce)");
+    return THEIA_OK;
+}
+
+// ================================================================================================
+// whole-sample LayerNorm over E = H*W*C elements, affine [E] (already permuted to NHWC order)
+// ================================================================================================
+constexpr int CHW_CHUNK = 8192;  // elements per block in the statistics passes (256 thr x 8 x 4)
+
+static int chw_chunks(int64_t E) { return (int)((E + CHW_CHUNK - 1) / CHW_CHUNK); }
+static int chw_groups(int b, int64_t E) {
+    // batch groups for the affine-gradient reduction: enough blocks to fill the chip, at most b
+    const int64_t col_blocks = (E / 8 + 255) / 256;
+    int64_t g = (1024 + col_blocks - 1) / col_blocks;
+    if (g > b) g = b;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" size_t theia_layernorm_chw_workspace_bytes(int b, int64_t E) {
+    const size_t stats = (((size_t)b * chw_chunks(E) * 2 + 63) / 64) * 64;  // floats: per-chunk partial sums
+    const size_t dstat = (((size_t)b * 2 + 63) / 64) * 64;                    // floats: per-sample backward means
+    const size_t parts = (size_t)chw_groups(b, E) * 2 * E;                   // floats: per-group affine-grad partials
+    return (stats + dstat + parts) * sizeof(float);
+}
+
+// partial (sum a, sum b) per (sample, chunk).  MODE 0: a = x, b = x*x.  MODE 1: a = dy*g, b = dy*g*xhat.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void chw_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                          const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                          float* __restrict__ part, int64_t E, int nchunks) {
+    __shared__ float red[8];
+    const int sample = blockIdx.y, chunk = blockIdx.x;
+    const int64_t base = (int64_t)sample * E;
+    float mu = 0.f, rs = 0.f;
+    if (MODE == 1) {
+        mu = stats[2 * sample];
+        rs = stats[2 * sample + 1];
+    }
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int it = 0; it < CHW_CHUNK / (256 * 8); ++it) {
+        const int64_t e = (int64_t)chunk * CHW_CHUNK + (it * 256 + threadIdx.x) * 8;
+        if (e < E) {
+            float xv[8];
+            load8(x + base + e, xv);
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    sa += xv[j];
+                    sb += xv[j] * xv[j];
+                }
+            } else {
+                float dv[8], g8[8];
+                load8(dy + base + e, dv);
+                load8(gamma + e, g8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gy = dv[j] * g8[j];
+                    sa += gy;
+                    sb += gy * (xv[j] - mu) * rs;
+                }
+            }
+        }
+    }
+    sa = block_sum<256>(sa, red);
+    sb = block_sum<256>(sb, red + 4);
+    if (threadIdx.x == 0) {
+        part[((int64_t)sample * nchunks + chunk) * 2] = sa;
+        part[((int64_t)sample * nchunks + chunk) * 2 + 1] = sb;
+    }
+}
+
+// MODE 0: stats[s] = (mean, rstd).  MODE 1: stats_out[s] = (mean(dy*g), mean(dy*g*xhat)).
+template <int MODE>
+__global__ void chw_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int b, int nchunks, int64_t E,
+                                    float eps) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= b) return;
+    double a = 0.0, q = 0.0;
+    for (int c = 0; c < nchunks; ++c) {
+        a += (double)part[((int64_t)s * nchunks + c) * 2];
+        q += (double)part[((int64_t)s * nchunks + c) * 2 + 1];
+    }
+    if (MODE == 0) {
+        const double mu = a / (double)E;
+        double var = q / (double)E - mu * mu;
+        if (var < 0.0) var = 0.0;
+        out[2 * s] = (float)mu;
+        out[2 * s + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+        out[2 * s] = (float)(a / (double)E);
+        out[2 * s + 1] = (float)(q / (double)E);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void chw_apply_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ stats,
+                                                        T* __restrict__ y, int64_t E) {
+    const int sample = blockIdx.y;
+    const float mu = stats[2 * sample], rs = stats[2 * sample + 1];
+    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (e >= E) return;
+    float xv[8], g8[8], b8[8], o[8];
+    load8(x + (int64_t)sample * E + e, xv);
+    load8(gamma + e, g8);
+    load8(beta + e, b8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (xv[j] - mu) * rs * g8[j] + b8[j];
+    store8(y + (int64_t)sample * E + e, o);
+}
+
+extern "C" int theia_layernorm_chw_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                                       float* workspace, int b, int64_t E, float eps, int dtype, void* stream) {
+    THEIA_CHECK_ARG(x && gamma && beta && y && stats && workspace, "theia_layernorm_chw_fwd: null pointer");
+    THEIA_CHECK_ARG(b > 0 && E > 0 && E % 8 == 0, "theia_layernorm_chw_fwd: E=%lld must be a positive multiple of 8", (long long)E);
+    THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16, "theia_layernorm_chw_fwd: bad dtype");
+    const int nch = chw_chunks(E);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == THEIA_BF16)
+        hipLaunchKernelGGL((chw_partial_kernel<bf16_t, 0>), dim3(nch, b), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, E, nch);
+    else
+        hipLaunchKernelGGL((chw_partial_kernel<float, 0>), dim3(nch, b), dim3(256), 0, s, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, E, nch);
+    THEIA_CHECK_LAUNCH("theia_layernorm_chw_fwd(partial)");
+    hipLaunchKernelGGL(chw_finalize_kernel<0>, dim3((b + 63) / 64), dim3(64), 0, s, workspace, stats, b, nch, E, eps);
+    THEIA_CHECK_LAUNCH("theia_layernorm_chw_fwd(finalize)");
+    const dim3 grid((unsigned)((E / 8 + 255) / 256), b);
+    if (dtype == THEIA_BF16)
+        hipLaunchKernelGGL(chw_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, stats, (bf16_t*)y, E);
+    else
+        hipLaunchKernelGGL(chw_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, gamma, beta, stats, (float*)y, E);
+    THEIA_CHECK_LAUNCH("theia_layernorm_chw_fwd(apply)");
+    return THEIA_OK;
+}
+
+// dx for a group of samples + partial affine gradients of that group
+template <typename T>
+__global__ __launch_bounds__(256) void chw_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                      const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                      const float* __restrict__ dstat, T* __restrict__ dx,
+                                                      float* __restrict__ part, int b, int64_t E, int ngroups, int relu_mask) {
+    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (e >= E) return;
+    const int grp = blockIdx.y;
+    const int per = (b + ngroups - 1) / ngroups;
+    const int s0 = grp * per, s1 = min(b, s0 + per);
+    float g8[8], ag[8], ab[8];
+    load8(gamma + e, g8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ag[j] = ab[j] = 0.f;
+    for (int s = s0; s < s1; ++s) {
+        const float mu = stats[2 * s], rs = stats[2 * s + 1];
+        const float m1 = dstat[2 * s], m2 = dstat[2 * s + 1];
+        float xv[8], dv[8], o[8];
+        load8(x + (int64_t)s * E + e, xv);
+        load8(dy + (int64_t)s * E + e, dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = (xv[j] - mu) * rs;
+            ag[j] += dv[j] * xh;
+            ab[j] += dv[j];
+            float d = rs * (dv[j] * g8[j] - m1 - xh * m2);
+            if (relu_mask && !(xv[j] > 0.f)) d = 0.f;
+            o[j] = d;
+        }
+        store8(dx + (int64_t)s * E + e, o);
+    }
+    float* pg = part + (int64_t)grp * 2 * E;
+    store8(pg + e, ag);
+    store8(pg + E + e, ab);
+}
+
+extern "C" int theia_layernorm_chw_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
+                                       float* dgamma, float* dbeta, float* workspace, int b, int64_t E, int relu_mask,
+                                       int accumulate, int dtype, void* stream) {
+    THEIA_CHECK_ARG(dy && x && gamma && stats && dx && dgamma && dbeta && workspace, "theia_layernorm_chw_bwd: null pointer");
+    THEIA_CHECK_ARG(b > 0 && E > 0 && E % 8 == 0, "theia_layernorm_chw_bwd: bad E");
+    THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16, "theia_layernorm_chw_bwd: bad dtype");
+    const int nch = chw_chunks(E);
+    const int ng = chw_groups(b, E);
+    // workspace layout (see theia_layernorm_chw_workspace_bytes): [partial stats | dstat | affine partials]
+    float* part_stats = workspace;
+    float* dstat = part_stats + (((size_t)b * nch * 2 + 63) / 64) * 64;
+    float* parts = dstat + (((size_t)b * 2 + 63) / 64) * 64;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == THEIA_BF16)
+        hipLaunchKernelGGL((chw_partial_kernel<bf16_t, 1>), dim3(nch, b), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, gamma, stats, part_stats, E, nch);
+    else
+        hipLaunchKernelGGL((chw_partial_kernel<float, 1>), dim3(nch, b), dim3(256), 0, s, (const float*)x, (const float*)dy, gamma, stats, part_stats, E, nch);
+    THEIA_CHECK_LAUNCH("theia_layernorm_chw_bwd(partial)");
+    hipLaunchKernelGGL(chw_finalize_kernel<1>, dim3((b + 63) / 64), dim3(64), 0, s, part_stats, dstat, b, nch, E, 0.f);
+    THEIA_CHECK_LAUNCH("theia_layernorm_chw_bwd(finalize)");
+    const dim3 grid((unsigned)((E / 8 + 255) / 256), ng);
+    if (dtype == THEIA_BF16)
+        hipLaunchKernelGGL(chw_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, stats, dstat, (bf16_t*)dx, parts, b, E, ng, relu_mask);
+    else
+        hipLaunchKernelGGL(chw_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, stats, dstat, (float*)dx, parts, b, E, ng, relu_mask);
+    THEIA_CHECK_LAUNCH("theia_layernorm_chw_bwd(dx)");
+    // reduce partials: columns [0,E) -> dgamma, [E,2E) -> dbeta
+    const int64_t ncol = 2 * E;
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, s, parts, ng, (int)ncol,
+                       (int64_t)2 * E, dgamma, dbeta, (int)E, accumulate);
+    THEIA_CHECK_LAUNCH("theia_layernorm_chw_bwd(reduce)");
+    return THEIA_OK;
+}

@@ -1,0 +1,329 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per kernel family) and the row-map builders
+that express Linear / Conv3x3 / ConvTranspose3x3 (+ data/weight gradients) as implicit GEMMs.
+
+Everything here launches HIP kernels on torch's current stream; nothing falls back to torch math.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as N
+from ._native import RowMap, GemmArgs, WgradArgs
+
+# ----------------------------------------------------------------------------------------------
+# row maps
+# ----------------------------------------------------------------------------------------------
+
+
+def rowmap(taps: Sequence[Tuple[int, int, int]], rows_hw: Tuple[int, int], in_hw: Tuple[int, int], in_s: int, in_c: int,
+           in_batch_stride: int, in_offset: int, out_w: int, out_s: int, out_y0: int, out_x0: int,
+           out_batch_stride: int, out_offset: int) -> RowMap:
+    """taps: (dy, dx, wslot) per tap."""
+    m = RowMap()
+    m.ntaps = len(taps)
+    for t, (dy, dx, ws) in enumerate(taps):
+        m.dy[t], m.dx[t], m.wslot[t] = dy, dx, ws
+    m.rows_h, m.rows_w = rows_hw
+    m.in_h, m.in_w = in_hw
+    m.in_sy = m.in_sx = in_s
+    m.in_c = in_c
+    m.out_w, m.out_sy, m.out_sx, m.out_y0, m.out_x0 = out_w, out_s, out_s, out_y0, out_x0
+    m.in_batch_stride, m.in_offset = in_batch_stride, in_offset
+    m.out_batch_stride, m.out_offset = out_batch_stride, out_offset
+    return m
+
+
+def rm_plain(K: int, lda: int, ldo: int, a_offset: int = 0, o_offset: int = 0) -> RowMap:
+    """Row-major [M,K] (pitch lda) -> [M,N] (pitch ldo)."""
+    return rowmap([(0, 0, 0)], (1, 1), (1, 1), 1, K, lda, a_offset, 1, 1, 0, 0, ldo, o_offset)
+
+
+TAPS9 = [(ky, kx) for ky in range(3) for kx in range(3)]
+
+
+@dataclass
+class ConvPlan:
+    """Row maps of one 3x3 (transposed) convolution on NHWC activations.
+
+    fwd: list of (rowmap, M_per_image) -- one entry, or 4 output-parity classes for stride-2 transposed convs
+    dgrad: (rowmap, M_per_image)
+    pack_fwd / pack_dgrad: (d0, d1, d2, s0, s1, s2) arguments of theia_cast_permute3 producing W[n][slot][c]
+    grad_strides: (sn, ss, sc) of theia_wgrad_reduce writing into the reference weight layout
+    """
+    fwd: List[Tuple[RowMap, int]]
+    dgrad: Tuple[RowMap, int]
+    pack_fwd: Tuple[int, int, int, int, int, int]
+    pack_dgrad: Tuple[int, int, int, int, int, int]
+    grad_strides: Tuple[int, int, int]
+    out_hw: int
+
+
+def plan_conv3x3(C: int, H: int, in_bs: Optional[int] = None, in_off: int = 0) -> ConvPlan:
+    """nn.Conv2d(C, C, 3, padding=1) on an HxH map; weight [co, ci, ky, kx] (adapter_heads.py:319-323)."""
+    bs = H * H * C
+    fwd = rowmap([(ky - 1, kx - 1, ky * 3 + kx) for ky, kx in TAPS9], (H, H), (H, H), 1, C, in_bs or bs, in_off, H, 1, 0, 0, bs, 0)
+    dg = rowmap([(1 - ky, 1 - kx, ky * 3 + kx) for ky, kx in TAPS9], (H, H), (H, H), 1, C, bs, 0, H, 1, 0, 0, in_bs or bs, in_off)
+    return ConvPlan([(fwd, H * H)], (dg, H * H), (C, 9, C, C * 9, 1, 9), (C, 9, C, 9, 1, C * 9), (C * 9, 1, 9), H)
+
+
+def plan_convT3x3(C: int, IH: int, stride: int, padding: int, output_padding: int, in_bs: Optional[int] = None,
+                  in_off: int = 0) -> ConvPlan:
+    """nn.ConvTranspose2d(C, C, 3, stride, padding, output_padding); weight [ci, co, ky, kx]
+    (adapter_heads.py:282-288 pad, :307-311 up-sampling).  out[i*s - p + ky] += in[i] * W[ky]."""
+    OH = (IH - 1) * stride - 2 * padding + 3 + output_padding
+    ibs = in_bs or IH * IH * C
+    obs = OH * OH * C
+    fwd: List[Tuple[RowMap, int]] = []
+    if stride == 1:
+        taps = [(padding - ky, padding - kx, ky * 3 + kx) for ky, kx in TAPS9]
+        fwd.append((rowmap(taps, (OH, OH), (IH, IH), 1, C, ibs, in_off, OH, 1, 0, 0, obs, 0), OH * OH))
+    else:
+        assert stride == 2
+        for py in range(2):
+            for px in range(2):
+                nyc, nxc = len(range(py, OH, 2)), len(range(px, OH, 2))
+                taps = []
+                for ky, kx in TAPS9:
+                    if (py + padding - ky) % 2 == 0 and (px + padding - kx) % 2 == 0:
+                        taps.append(((py + padding - ky) // 2, (px + padding - kx) // 2, ky * 3 + kx))
+                fwd.append((rowmap(taps, (nyc, nxc), (IH, IH), 1, C, ibs, in_off, OH, 2, py, px, obs, 0), nyc * nxc))
+    # d in[i,j] = sum_{ky,kx} d out[i*s - p + ky, j*s - p + kx] . W[ci, :, ky, kx]
+    dg = rowmap([(ky - padding, kx - padding, ky * 3 + kx) for ky, kx in TAPS9], (IH, IH), (OH, OH), stride, C, obs, 0,
+                IH, 1, 0, 0, ibs, in_off)
+    return ConvPlan(fwd, (dg, IH * IH), (C, 9, C, 9, 1, C * 9), (C, 9, C, C * 9, 1, 9), (9, 1, C * 9), OH)
+
+
+# ----------------------------------------------------------------------------------------------
+# kernel wrappers
+# ----------------------------------------------------------------------------------------------
+
+
+def _dt(t: torch.Tensor) -> int:
+    return N.dtype_code(t.dtype)
+
+
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int, K: int, rmap: RowMap, ldw: int, ldo: int,
+            bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, act: int = N.ACT_NONE,
+            aux_in: Optional[torch.Tensor] = None, aux_out: Optional[torch.Tensor] = None,
+            rowtab: Optional[torch.Tensor] = None, rowtab_period: int = 0) -> torch.Tensor:
+    g = GemmArgs()
+    g.a, g.w, g.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    g.bias, g.resid, g.aux_in, g.aux_out = N.ptr(bias), N.ptr(resid), N.ptr(aux_in), N.ptr(aux_out)
+    g.rowtab, g.rowtab_period = N.ptr(rowtab), rowtab_period
+    g.M, g.N, g.K, g.ldw, g.ldo, g.act = M, Nn, K, ldw, ldo, act
+    g.map = rmap
+    assert a.dtype == w.dtype == out.dtype
+    N.check(N.lib().theia_gemm_nt(g, _dt(a), N.stream_ptr()), "theia_gemm_nt")
+    return out
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
+           act: int = N.ACT_NONE, aux_in: Optional[torch.Tensor] = None, aux_out: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act(x @ w.T + bias) + resid ; x [M,K], w [N,K] contiguous."""
+    M, K = x.shape
+    Nn = w.shape[0]
+    if out is None:
+        out = torch.empty(M, Nn, dtype=x.dtype, device=x.device)
+    return gemm_nt(x, w, out, M, Nn, K, rm_plain(K, x.stride(0), out.stride(0)), w.stride(0), out.stride(0), bias, resid, act,
+                   aux_in, aux_out)
+
+
+def gemm_wgrad(dy: torch.Tensor, a: torch.Tensor, slabs: torch.Tensor, M: int, Nn: int, ldo: int, kslots: int, splits: int,
+               rmap: RowMap) -> None:
+    g = WgradArgs()
+    g.dy, g.a, g.slabs = dy.data_ptr(), a.data_ptr(), slabs.data_ptr()
+    g.M, g.N, g.ldo, g.kslots, g.splits = M, Nn, ldo, kslots, splits
+    g.map = rmap
+    N.check(N.lib().theia_gemm_wgrad(g, _dt(dy), N.stream_ptr()), "theia_gemm_wgrad")
+
+
+def wgrad_splits(M: int, Nn: int, Ktot: int) -> int:
+    return N.lib().theia_wgrad_splits(M, Nn, Ktot)
+
+
+def wgrad_reduce(slabs: torch.Tensor, splits: int, Nn: int, kslots: int, C: int, out: torch.Tensor, sn: int, ss: int, sc: int,
+                 accumulate: bool) -> None:
+    N.check(N.lib().theia_wgrad_reduce(slabs.data_ptr(), splits, Nn, kslots, C, out.data_ptr(), sn, ss, sc, int(accumulate),
+                                       N.stream_ptr()), "theia_wgrad_reduce")
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, grad_w: torch.Tensor, accumulate: bool,
+                 ws: Optional[torch.Tensor] = None) -> None:
+    """grad_w[N,K] (+)= dy[M,N]^T @ x[M,K]."""
+    M, Nn = dy.shape
+    K = x.shape[1]
+    splits = wgrad_splits(M, Nn, K)
+    need = splits * Nn * K
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=dy.device)
+    gemm_wgrad(dy, x, ws, M, Nn, dy.stride(0), 1, splits, rm_plain(K, x.stride(0), dy.stride(0)))
+    wgrad_reduce(ws, splits, Nn, 1, K, grad_w, K, 0, 1, accumulate)
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool, ws: Optional[torch.Tensor] = None) -> None:
+    M, Nn = x.shape
+    need = N.lib().theia_colsum_workspace_bytes(M, Nn) // 4
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=x.device)
+    N.check(N.lib().theia_colsum(x.data_ptr(), M, Nn, x.stride(0), out.data_ptr(), ws.data_ptr(), int(accumulate), _dt(x),
+                                 N.stream_ptr()), "theia_colsum")
+
+
+def cast(src: torch.Tensor, dst: torch.Tensor) -> None:
+    N.check(N.lib().theia_cast(src.data_ptr(), dst.data_ptr(), src.numel(), _dt(dst), N.stream_ptr()), "theia_cast")
+
+
+def cast_transpose(src: torch.Tensor, dst: torch.Tensor, ldd: Optional[int] = None) -> None:
+    R, Cc = src.shape
+    N.check(N.lib().theia_cast_transpose(src.data_ptr(), dst.data_ptr(), R, Cc, ldd or R, _dt(dst), N.stream_ptr()),
+            "theia_cast_transpose")
+
+
+def cast_permute3(src: torch.Tensor, dst: torch.Tensor, d0: int, d1: int, d2: int, s0: int, s1: int, s2: int) -> None:
+    N.check(N.lib().theia_cast_permute3(src.data_ptr(), dst.data_ptr(), d0, d1, d2, s0, s1, s2, _dt(dst), N.stream_ptr()),
+            "theia_cast_permute3")
+
+
+def unpermute3(src: torch.Tensor, dst: torch.Tensor, d0: int, d1: int, d2: int, t0: int, t1: int, t2: int,
+               accumulate: bool) -> None:
+    N.check(N.lib().theia_unpermute3_f32(src.data_ptr(), dst.data_ptr(), d0, d1, d2, t0, t1, t2, int(accumulate),
+                                         N.stream_ptr()), "theia_unpermute3_f32")
+
+
+def patchify(img: torch.Tensor, lut: torch.Tensor, out: torch.Tensor, channels_last: bool) -> None:
+    b = img.shape[0]
+    N.check(N.lib().theia_patchify_u8(img.data_ptr(), lut.data_ptr(), out.data_ptr(), b, int(channels_last), _dt(out),
+                                      N.stream_ptr()), "theia_patchify_u8")
+
+
+def write_cls(cls: torch.Tensor, pos: torch.Tensor, h: torch.Tensor, b: int, ntok: int, D: int) -> None:
+    N.check(N.lib().theia_write_cls(cls.data_ptr(), pos.data_ptr(), h.data_ptr(), b, ntok, D, _dt(h), N.stream_ptr()),
+            "theia_write_cls")
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
+    M, D = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    N.check(N.lib().theia_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                        rstd.data_ptr(), M, D, eps, _dt(x), N.stream_ptr()), "theia_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dresid, dgamma, dbeta, accumulate: bool, ws: Optional[torch.Tensor] = None):
+    M, D = x.shape
+    dx = torch.empty_like(x)
+    need = N.lib().theia_layernorm_bwd_workspace_bytes(M, D) // 4
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=x.device)
+    N.check(N.lib().theia_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                        N.ptr(dresid), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), M, D,
+                                        int(accumulate), _dt(x), N.stream_ptr()), "theia_layernorm_bwd")
+    return dx
+
+
+def layernorm_chw_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, ws: Optional[torch.Tensor] = None):
+    """x [b, E] (NHWC flattened); gamma/beta f32 [E] in NHWC order."""
+    b, E = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty(b, 2, dtype=torch.float32, device=x.device)
+    need = N.lib().theia_layernorm_chw_workspace_bytes(b, E) // 4
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=x.device)
+    N.check(N.lib().theia_layernorm_chw_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(),
+                                            ws.data_ptr(), b, E, eps, _dt(x), N.stream_ptr()), "theia_layernorm_chw_fwd")
+    return y, stats
+
+
+def layernorm_chw_bwd(dy, x, gamma, stats, dgamma, dbeta, relu_mask: bool, accumulate: bool, ws: Optional[torch.Tensor] = None):
+    b, E = x.shape
+    dx = torch.empty_like(x)
+    need = N.lib().theia_layernorm_chw_workspace_bytes(b, E) // 4
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=x.device)
+    N.check(N.lib().theia_layernorm_chw_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats.data_ptr(), dx.data_ptr(),
+                                            dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), b, E, int(relu_mask),
+                                            int(accumulate), _dt(x), N.stream_ptr()), "theia_layernorm_chw_bwd")
+    return dx
+
+
+def attention_fwd(qkv: torch.Tensor, b: int, n: int, h: int):
+    D = h * 64
+    o = torch.empty(b * n, D, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(b * h * n, dtype=torch.float32, device=qkv.device)
+    N.check(N.lib().theia_attention_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), b, n, h, _dt(qkv), N.stream_ptr()),
+            "theia_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(qkv, o, d_o, lse, b: int, n: int, h: int, ws: Optional[torch.Tensor] = None):
+    dqkv = torch.empty_like(qkv)
+    need = b * n * h
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=qkv.device)
+    N.check(N.lib().theia_attention_bwd(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                        ws.data_ptr(), b, n, h, _dt(qkv), N.stream_ptr()), "theia_attention_bwd")
+    return dqkv
+
+
+def distill_loss_fwd(pred: torch.Tensor, target: torch.Tensor, ws: Optional[torch.Tensor] = None):
+    """pred [b, E] (compute dtype), target [b, E] f32 -> (losses f32[3] = (mse, cos, l1), coef f32 [b,2])."""
+    b, E = pred.shape
+    losses = torch.empty(3, dtype=torch.float32, device=pred.device)
+    coef = torch.empty(b, 2, dtype=torch.float32, device=pred.device)
+    need = N.lib().theia_distill_loss_workspace_bytes(b, E) // 4
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=pred.device)
+    N.check(N.lib().theia_distill_loss_fwd(pred.data_ptr(), target.data_ptr(), losses.data_ptr(), coef.data_ptr(), ws.data_ptr(),
+                                           b, E, _dt(pred), N.stream_ptr()), "theia_distill_loss_fwd")
+    return losses, coef
+
+
+def distill_loss_bwd(pred: torch.Tensor, target: torch.Tensor, coef: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    b, E = pred.shape
+    dpred = torch.empty_like(pred)
+    N.check(N.lib().theia_distill_loss_bwd(pred.data_ptr(), target.data_ptr(), coef.data_ptr(), w.data_ptr(), dpred.data_ptr(), b,
+                                           E, _dt(pred), N.stream_ptr()), "theia_distill_loss_bwd")
+    return dpred
+
+
+def token_select(x: torch.Tensor, b: int, n: int, D: int, disc: int, mode: int) -> torch.Tensor:
+    shape = (b, n - 1 - disc, D) if mode == 0 else (b, D)
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    N.check(N.lib().theia_token_select(x.data_ptr(), out.data_ptr(), b, n, D, disc, mode, _dt(x), N.stream_ptr()),
+            "theia_token_select")
+    return out
+
+
+def feature_norm_bf16(x_bf16: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> torch.Tensor:
+    rows, Cc = x_bf16.shape
+    out = torch.empty(rows, Cc, dtype=torch.float32, device=x_bf16.device)
+    N.check(N.lib().theia_feature_norm_bf16(x_bf16.data_ptr(), mean.data_ptr(), std.data_ptr(), out.data_ptr(), rows, Cc,
+                                            N.stream_ptr()), "theia_feature_norm_bf16")
+    return out
+
+
+def add_inplace(dst: torch.Tensor, src: torch.Tensor) -> None:
+    N.check(N.lib().theia_add_inplace(dst.data_ptr(), src.data_ptr(), dst.numel(), _dt(dst), N.stream_ptr()), "theia_add_inplace")
+
+
+def fill_zero(t: torch.Tensor) -> None:
+    N.check(N.lib().theia_fill_zero(t.data_ptr(), t.numel() * t.element_size(), N.stream_ptr()), "theia_fill_zero")
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step: int, grad_scale: float = 1.0) -> None:
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    N.check(N.lib().theia_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps, wd,
+                                     bc1, bc2, grad_scale, N.stream_ptr()), "theia_adamw_step")
+
+
+def probe_tr16(image: torch.Tensor, addr: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(256, dtype=torch.int16, device=image.device)
+    N.check(N.lib().theia_probe_tr16(image.data_ptr(), addr.data_ptr(), out.data_ptr(), N.stream_ptr()), "theia_probe_tr16")
+    return out
