@@ -1,0 +1,591 @@
+"""StudentEngine: drives the HIP kernels for the Theia hot path (forward AND hand-written backward).
+
+    uint8 images --patchify/LUT--> patch GEMM (+bias +pos) --> 12 x {LN, QKV GEMM, attention, out-proj GEMM(+res),
+    LN, FC1 GEMM(+GELU), FC2 GEMM(+res)} --> LN --> per-teacher heads {pad ConvT, LN_chw, conv/convT(+ReLU) x2,
+    LN_chw, Linear} --> distillation loss
+
+The engine owns no parameters: it reads the fp32 master parameters held by ``RobotVisionFM`` (reference state_dict
+layout), derives the operand layouts the kernels want (bf16/f32 casts, [co][tap][ci] conv packs, transposes for
+data-gradients) into an operand cache that is refreshed when a parameter changes, and writes gradients straight
+into flat per-bucket gradient buffers (``param.grad`` become views of them) so that data-parallel all-reduce can
+run bucket-by-bucket while the rest of backward is still executing.
+
+Autograd sees three nodes (backbone, translator, per-teacher loss); inside a node everything is explicit HIP
+launches on the current stream -- there is no torch math and no CPU fallback on the product path.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import ops
+from .models.backbones import GRID, IMAGE, NTOK, NUM_LAYERS
+
+# bumped by optimizers that update parameters through raw pointers (torch's version counter does not see those)
+PARAM_EPOCH = [0]
+
+LN_EPS_VIT = 1e-12   # ViTConfig.layer_norm_eps
+LN_EPS_HEAD = 1e-5   # nn.LayerNorm default (adapter_heads.py:306-324)
+
+
+def preprocess_lut(do_rescale: bool, do_normalize: bool, mean: Sequence[float], std: Sequence[float]) -> np.ndarray:
+    """[3,256] f32 table reproducing the HF processor arithmetic bit-for-bit (host side, 768 values):
+    rescale = float32(float64(v) * (1/255)) (transformers image_transforms.py:118-122), normalize = float32
+    (x - mean) / std with float32 mean/std (:419-439).  Reference call site: models/backbones.py:337-339."""
+    v = np.arange(256, dtype=np.uint8)
+    lut = np.zeros((3, 256), dtype=np.float32)
+    for c in range(3):
+        x = v
+        if do_rescale:
+            x = (x.astype(np.float64) * (1.0 / 255.0)).astype(np.float32)
+        if do_normalize:
+            if not np.issubdtype(x.dtype, np.floating):
+                x = x.astype(np.float32)
+            x = (x - np.array(mean[c], dtype=x.dtype)) / np.array(std[c], dtype=x.dtype)
+        lut[c] = x.astype(np.float32)
+    return lut
+
+
+def to_uint8_batch(x: Any) -> Tuple[torch.Tensor, bool]:
+    """Accepts what the reference's DeiT.forward accepts (uint8 torch [B,H,W,C] / [B,C,H,W], single image, numpy,
+    list of PIL images / arrays).  Returns (uint8 tensor, channels_last).  Channel layout inference follows
+    transformers image_utils.infer_channel_dimension_format: a leading dim of 1/3 means channels-first."""
+    if isinstance(x, (list, tuple)):
+        items = [to_uint8_batch(i) for i in x]
+        cl = items[0][1]
+        ts = [t if c == cl else (t.permute(0, 2, 3, 1) if cl else t.permute(0, 3, 1, 2)) for t, c in items]
+        return torch.cat(ts, 0).contiguous(), cl
+    if not isinstance(x, (torch.Tensor, np.ndarray)):
+        x = np.asarray(x)  # PIL
+        if x.ndim == 2:
+            x = np.stack([x] * 3, -1)
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    if x.dim() == 3:
+        x = x.unsqueeze(0)
+    if x.dim() != 4:
+        raise ValueError(f"expected a 3-D or 4-D image tensor, got shape {tuple(x.shape)}")
+    if x.dtype != torch.uint8:
+        raise TypeError("the MI355X ingest kernel takes uint8 pixels in [0,255] (reference default input)")
+    channels_last = not (x.shape[1] in (1, 3))
+    if (channels_last and x.shape[-1] != 3) or (not channels_last and x.shape[1] != 3):
+        raise ValueError(f"expected 3-channel images, got shape {tuple(x.shape)}")
+    hh, ww = (x.shape[1], x.shape[2]) if channels_last else (x.shape[2], x.shape[3])
+    if hh != IMAGE or ww != IMAGE:
+        raise NotImplementedError(f"{hh}x{ww} input: resize / crop / pos-emb interpolation are outside the hot path "
+                                  f"(SURVEY.md sec. 8f-3); feed {IMAGE}x{IMAGE} images")
+    return x.contiguous(), channels_last
+
+
+class GradBucket:
+    """A flat fp32 gradient buffer for a group of parameters, filled in backward-completion order."""
+
+    def __init__(self, name: str, params: List[torch.nn.Parameter]):
+        self.name = name
+        self.params = params
+        self.offsets: List[int] = []
+        off = 0
+        for p in params:
+            self.offsets.append(off)
+            off += (p.numel() + 7) // 8 * 8  # keep every view 32-byte aligned for vector stores
+        self.numel = off
+        self.flat: Optional[torch.Tensor] = None
+
+    def ensure(self, device) -> torch.Tensor:
+        if self.flat is None or self.flat.device != device:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        return self.flat
+
+    def view(self, i: int) -> torch.Tensor:
+        p = self.params[i]
+        return self.flat[self.offsets[i]:self.offsets[i] + p.numel()].view(p.shape)
+
+
+class StudentEngine:
+    def __init__(self, rvfm, precision: str = "fp32"):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' (exact-f32 MFMA, parity mode) or 'bf16' (throughput mode)")
+        self.rvfm = rvfm
+        self.dtype = torch.float32 if precision == "fp32" else torch.bfloat16
+        self.precision = precision
+        vit = rvfm.backbone.model
+        self.D, self.heads, self.F = vit.hidden_size, vit.num_heads, vit.intermediate_size
+        self._opcache: Dict[str, torch.Tensor] = {}
+        self._opkey = None
+        self._ws: Optional[torch.Tensor] = None
+        self._luts: Dict[Tuple[bool, bool], torch.Tensor] = {}
+        self._plans: Dict[str, Any] = {}
+        self.buckets: List[GradBucket] = []
+        self._bucket_of: Dict[int, Tuple[GradBucket, int]] = {}
+        self.bucket_ready_hook: Optional[Callable[[GradBucket], None]] = None
+        self._build_buckets()
+
+    # ------------------------------------------------------------------ parameters & buckets
+    def head_modules(self):
+        tr = getattr(self.rvfm, "translator", None)
+        if tr is None:
+            return []
+        return [(t, tr.translator_heads[tr.legit_target_model_name_map[t]]) for t in tr.target_model_names]
+
+    def _build_buckets(self) -> None:
+        """Backward-completion order: heads (in forward order), then backbone layer groups from the top down."""
+        self.buckets = []
+        for t, hm in self.head_modules():
+            self.buckets.append(GradBucket(f"head:{t}", list(hm.parameters())))
+        vit = self.rvfm.backbone.model
+        groups = [(9, 12), (6, 9), (3, 6), (0, 3)]
+        for gi, (lo, hi) in enumerate(groups):
+            ps: List[torch.nn.Parameter] = []
+            if gi == 0:
+                ps += list(vit.layernorm.parameters())
+            for li in range(hi - 1, lo - 1, -1):
+                ps += list(vit.layers[li].parameters())
+            if lo == 0:
+                ps += list(vit.embeddings.parameters())
+            self.buckets.append(GradBucket(f"vit:{lo}-{hi - 1}", ps))
+        self._bucket_of = {}
+        for b in self.buckets:
+            for i, p in enumerate(b.params):
+                self._bucket_of[id(p)] = (b, i)
+
+    def all_params(self) -> List[torch.nn.Parameter]:
+        return [p for b in self.buckets for p in b.params]
+
+    def _grad(self, p: torch.nn.Parameter) -> Tuple[torch.Tensor, bool]:
+        """(view of the flat bucket for p, accumulate?) and makes p.grad that view."""
+        b, i = self._bucket_of[id(p)]
+        b.ensure(p.device)
+        v = b.view(i)
+        if p.grad is None:
+            p.grad = v
+            return v, False
+        if p.grad.data_ptr() != v.data_ptr():
+            v.copy_(p.grad)  # foreign .grad tensor: adopt it (rare path, plain copy)
+            p.grad = v
+        return v, True
+
+    def _bucket_done(self, b: GradBucket) -> None:
+        if self.bucket_ready_hook is not None:
+            self.bucket_ready_hook(b)
+
+    # ------------------------------------------------------------------ small helpers
+    def ws(self, nfloats: int, device) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nfloats or self._ws.device != device:
+            self._ws = torch.empty(max(nfloats, 1 << 20), dtype=torch.float32, device=device)
+        return self._ws
+
+    def _lut(self, do_rescale: bool, do_normalize: bool, device) -> torch.Tensor:
+        k = (do_rescale, do_normalize)
+        t = self._luts.get(k)
+        if t is None or t.device != device:
+            bb = self.rvfm.backbone
+            t = torch.from_numpy(preprocess_lut(do_rescale, do_normalize, bb.image_mean, bb.image_std)).to(device)
+            self._luts[k] = t
+        return t
+
+    def _plan(self, key: str):
+        if key not in self._plans:
+            C = self.D
+            if key == "pad":
+                self._plans[key] = ops.plan_convT3x3(C, GRID, 1, 0, 0, in_bs=NTOK * C, in_off=C)
+            elif key == "conv16":
+                self._plans[key] = ops.plan_conv3x3(C, 16)
+            elif key == "up31":
+                self._plans[key] = ops.plan_convT3x3(C, 16, 2, 1, 0)
+            elif key == "up64":
+                self._plans[key] = ops.plan_convT3x3(C, 31, 2, 0, 1)
+            elif key == "patch":
+                D = self.D
+                self._plans[key] = ops.rowmap([(0, 0, 0)], (GRID, GRID), (GRID, GRID), 1, 768, GRID * GRID * 768, 0, GRID, 1, 0, 0,
+                                              NTOK * D, D)
+        return self._plans[key]
+
+    # ------------------------------------------------------------------ operand cache
+    def _operands(self, device) -> Dict[str, torch.Tensor]:
+        params = self.all_params()
+        key = (device, self.dtype, PARAM_EPOCH[0]) + tuple((p._version, p.data_ptr()) for p in params)
+        if key == self._opkey:
+            return self._opcache
+        T, D, F = self.dtype, self.D, self.F
+        oc: Dict[str, torch.Tensor] = {}
+
+        def new(name, *shape, dtype=T):
+            t = self._opcache.get(name)
+            if t is None or t.shape != tuple(shape) or t.dtype != dtype or t.device != device:
+                t = torch.empty(*shape, dtype=dtype, device=device)
+            oc[name] = t
+            return t
+
+        vit = self.rvfm.backbone.model
+        ops.cast(vit.embeddings.patch_embeddings.projection.weight, new("patch.w", D, 768))
+        for i, L in enumerate(vit.layers):
+            a = L.attention
+            wqkv = new(f"l{i}.wqkv", 3 * D, D)
+            wqkvT = new(f"l{i}.wqkvT", D, 3 * D)
+            bqkv = new(f"l{i}.bqkv", 3 * D, dtype=torch.float32)
+            for j, prj in enumerate((a.q_proj, a.k_proj, a.v_proj)):
+                ops.cast(prj.weight, wqkv[j * D:(j + 1) * D])
+                ops.cast_transpose(prj.weight, wqkvT[:, j * D:], ldd=3 * D)
+                ops.cast(prj.bias, bqkv[j * D:(j + 1) * D])
+            ops.cast(a.o_proj.weight, new(f"l{i}.wo", D, D))
+            ops.cast_transpose(a.o_proj.weight, new(f"l{i}.woT", D, D))
+            ops.cast(L.mlp.fc1.weight, new(f"l{i}.w1", F, D))
+            ops.cast_transpose(L.mlp.fc1.weight, new(f"l{i}.w1T", D, F))
+            ops.cast(L.mlp.fc2.weight, new(f"l{i}.w2", D, F))
+            ops.cast_transpose(L.mlp.fc2.weight, new(f"l{i}.w2T", F, D))
+        C = D
+        for t, hm in self.head_modules():
+            pf = f"h:{t}."
+            pad_plan = self._plan("pad")
+            ops.cast_permute3(hm.pad["1"].weight, new(pf + "pad.wf", C, 9 * C), *pad_plan.pack_fwd)
+            ops.cast_permute3(hm.pad["1"].weight, new(pf + "pad.wd", C, 9 * C), *pad_plan.pack_dgrad)
+            for idx, pk in (("1", "up31"), ("4", "up64")) if hm.kind == "up64" else (("1", "conv16"), ("4", "conv16")):
+                pl = self._plan(pk)
+                ops.cast_permute3(hm.adapter[idx].weight, new(pf + f"c{idx}.wf", C, 9 * C), *pl.pack_fwd)
+                ops.cast_permute3(hm.adapter[idx].weight, new(pf + f"c{idx}.wd", C, 9 * C), *pl.pack_dgrad)
+            for idx, hw in zip(("0", "3", "6"), hm.sizes):
+                HW = hw * hw
+                ops.cast_permute3(hm.adapter[idx].weight, new(pf + f"ln{idx}.g", HW * C, dtype=torch.float32), HW, 1, C, 1, 0, HW)
+                ops.cast_permute3(hm.adapter[idx].bias, new(pf + f"ln{idx}.b", HW * C, dtype=torch.float32), HW, 1, C, 1, 0, HW)
+            Ct = hm.adapter["8"].weight.shape[0]
+            ops.cast(hm.adapter["8"].weight, new(pf + "w8", Ct, C))
+            ops.cast_transpose(hm.adapter["8"].weight, new(pf + "w8T", C, Ct))
+        self._opcache = oc
+        self._opkey = key
+        return oc
+
+    # ================================================================== backbone
+    def backbone(self, x: Any, do_rescale: bool = True, do_normalize: bool = True) -> torch.Tensor:
+        vit = self.rvfm.backbone.model
+        device = vit.layernorm.weight.device
+        if device.type != "cuda":
+            raise RuntimeError("theia_amd runs on a ROCm GPU only: move the model with .to('cuda') (no CPU fallback)")
+        img, channels_last = to_uint8_batch(x)
+        img = img.to(device, non_blocking=True)
+        params = list(vit.parameters())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _BackboneFn.apply(self, img, channels_last, do_rescale, do_normalize, *params)
+        z, _ = self._backbone_fwd(img, channels_last, do_rescale, do_normalize, save=False)
+        return z
+
+    def _backbone_fwd(self, img: torch.Tensor, channels_last: bool, do_rescale: bool, do_normalize: bool, save: bool):
+        dev, T, D, F, nh = img.device, self.dtype, self.D, self.F, self.heads
+        oc = self._operands(dev)
+        vit = self.rvfm.backbone.model
+        emb = vit.embeddings
+        b = img.shape[0]
+        M = b * NTOK
+        patches = torch.empty(b * GRID * GRID, 768, dtype=T, device=dev)
+        ops.patchify(img, self._lut(do_rescale, do_normalize, dev), patches, channels_last)
+        h = torch.empty(M, D, dtype=T, device=dev)
+        pos = emb.position_embeddings
+        ops.gemm_nt(patches, oc["patch.w"], h, b * GRID * GRID, D, 768, self._plan("patch"), 768, D,
+                    bias=emb.patch_embeddings.projection.bias, rowtab=pos.view(NTOK, D)[1:], rowtab_period=GRID * GRID)
+        ops.write_cls(emb.cls_token, pos, h, b, NTOK, D)
+        saved: Dict[str, Any] = {"b": b, "patches": patches if save else None, "layers": []}
+        for i, L in enumerate(vit.layers):
+            a, mean1, rstd1 = ops.layernorm_fwd(h, L.layernorm_before.weight, L.layernorm_before.bias, LN_EPS_VIT)
+            qkv = ops.linear(a, oc[f"l{i}.wqkv"], oc[f"l{i}.bqkv"])
+            o, lse = ops.attention_fwd(qkv, b, NTOK, nh)
+            h1 = ops.linear(o, oc[f"l{i}.wo"], L.attention.o_proj.bias, resid=h)
+            m, mean2, rstd2 = ops.layernorm_fwd(h1, L.layernorm_after.weight, L.layernorm_after.bias, LN_EPS_VIT)
+            pre = torch.empty(M, F, dtype=T, device=dev) if save else None
+            act = ops.linear(m, oc[f"l{i}.w1"], L.mlp.fc1.bias, act=N.ACT_GELU, aux_out=pre)
+            h2 = ops.linear(act, oc[f"l{i}.w2"], L.mlp.fc2.bias, resid=h1)
+            if save:
+                saved["layers"].append((h, mean1, rstd1, a, qkv, o, lse, h1, mean2, rstd2, m, pre, act))
+            h = h2
+        z, meanf, rstdf = ops.layernorm_fwd(h, vit.layernorm.weight, vit.layernorm.bias, LN_EPS_VIT)
+        if save:
+            saved["final"] = (h, meanf, rstdf)
+        return z.view(b, NTOK, D), saved
+
+    def _backbone_bwd(self, saved: Dict[str, Any], dz: torch.Tensor) -> None:
+        dev, T, D, F, nh = dz.device, self.dtype, self.D, self.F, self.heads
+        oc = self._operands(dev)
+        vit = self.rvfm.backbone.model
+        b = saved["b"]
+        M = b * NTOK
+        dz = dz.contiguous().view(M, D)
+        if dz.dtype != T:
+            raise TypeError(f"gradient dtype {dz.dtype} does not match the engine's compute dtype {T}")
+        wsz = max(N.lib().theia_layernorm_bwd_workspace_bytes(M, D) // 4, N.lib().theia_colsum_workspace_bytes(M, F) // 4,
+                  N.lib().theia_colsum_workspace_bytes(b, NTOK * D) // 4,
+                  max(ops.wgrad_splits(M, n_, k_) * n_ * k_ for n_, k_ in ((D, F), (F, D), (D, D), (D, 768))))
+        ws = self.ws(wsz, dev)
+
+        def wgrad(dy, x, p):
+            g, acc = self._grad(p)
+            ops.linear_wgrad(dy, x, g, acc, ws)
+
+        def bgrad(dy, p):
+            g, acc = self._grad(p)
+            ops.colsum(dy, g, acc, ws)
+
+        hL, meanf, rstdf = saved["final"]
+        gw, accw = self._grad(vit.layernorm.weight)
+        gb, accb = self._grad(vit.layernorm.bias)
+        assert accw == accb
+        dh = ops.layernorm_bwd(dz, hL, vit.layernorm.weight, meanf, rstdf, None, gw, gb, accw, ws)
+        vit_buckets = [bk for bk in self.buckets if bk.name.startswith("vit:")]  # layer groups 9-11, 6-8, 3-5, 0-2
+        group_lo = {9: vit_buckets[0], 6: vit_buckets[1], 3: vit_buckets[2]}
+        for i in range(NUM_LAYERS - 1, -1, -1):
+            L = vit.layers[i]
+            (h, mean1, rstd1, a, qkv, o, lse, h1, mean2, rstd2, m, pre, act) = saved["layers"][i]
+            saved["layers"][i] = None
+            # h2 = h1 + fc2(act)
+            wgrad(dh, act, L.mlp.fc2.weight)
+            bgrad(dh, L.mlp.fc2.bias)
+            dpre = ops.linear(dh, oc[f"l{i}.w2T"], None, act=N.ACT_MUL_DGELU, aux_in=pre)
+            del act, pre
+            wgrad(dpre, m, L.mlp.fc1.weight)
+            bgrad(dpre, L.mlp.fc1.bias)
+            dm = ops.linear(dpre, oc[f"l{i}.w1T"])
+            del dpre
+            g2w, acc = self._grad(L.layernorm_after.weight)
+            g2b, _ = self._grad(L.layernorm_after.bias)
+            dh1 = ops.layernorm_bwd(dm, h1, L.layernorm_after.weight, mean2, rstd2, dh, g2w, g2b, acc, ws)
+            del dm, dh
+            # h1 = h + o_proj(o)
+            wgrad(dh1, o, L.attention.o_proj.weight)
+            bgrad(dh1, L.attention.o_proj.bias)
+            do = ops.linear(dh1, oc[f"l{i}.woT"])
+            dqkv = ops.attention_bwd(qkv, o, do, lse, b, NTOK, nh, ws)
+            del do
+            for j, prj in enumerate((L.attention.q_proj, L.attention.k_proj, L.attention.v_proj)):
+                sl = dqkv[:, j * D:(j + 1) * D]
+                wgrad(sl, a, prj.weight)
+                bgrad(sl, prj.bias)
+            da = ops.linear(dqkv, oc[f"l{i}.wqkvT"])
+            del dqkv
+            g1w, acc = self._grad(L.layernorm_before.weight)
+            g1b, _ = self._grad(L.layernorm_before.bias)
+            dh = ops.layernorm_bwd(da, h, L.layernorm_before.weight, mean1, rstd1, dh1, g1w, g1b, acc, ws)
+            del da, dh1
+            if i in group_lo:
+                self._bucket_done(group_lo[i])
+        # embeddings: h0[b, 0] = cls + pos[0];  h0[b, 1+p] = patches @ Wp^T + bias + pos[1+p]
+        emb = vit.embeddings
+        gpos, acc = self._grad(emb.position_embeddings)
+        ops.colsum(dh.view(b, NTOK * D), gpos.view(NTOK * D), acc, ws)
+        gcls, acc = self._grad(emb.cls_token)
+        ops.colsum(dh.view(b, NTOK * D)[:, :D], gcls.view(D), acc, ws)
+        gpb, acc = self._grad(emb.patch_embeddings.projection.bias)
+        # bias gradient = sum over images and patch tokens: two column sums (tokens of one image, then images)
+        tmp = torch.empty(NTOK * D, dtype=torch.float32, device=dev)
+        ops.colsum(dh.view(b, NTOK * D), tmp, False, ws)
+        ops.colsum(tmp.view(NTOK, D)[1:], gpb, acc, ws)
+        gpw, acc = self._grad(emb.patch_embeddings.projection.weight)
+        rmap = self._plan("patch")
+        Mp = b * GRID * GRID
+        splits = ops.wgrad_splits(Mp, D, 768)
+        slabs = ws[: splits * D * 768]
+        ops.gemm_wgrad(dh, saved["patches"], slabs, Mp, D, D, 1, splits, rmap)
+        ops.wgrad_reduce(slabs, splits, D, 1, 768, gpw, 768, 0, 1, acc)
+        self._bucket_done(vit_buckets[3])
+
+    # ================================================================== translator heads
+    def translator(self, z: torch.Tensor, names: List[str]) -> Dict[str, torch.Tensor]:
+        tr = self.rvfm.translator
+        for t in names:
+            if t not in tr.legit_target_model_name_map:
+                raise KeyError(t)
+        head_params: List[torch.nn.Parameter] = []
+        for t in names:
+            head_params += list(tr.translator_heads[tr.legit_target_model_name_map[t]].parameters())
+        if z.dtype != self.dtype:
+            raise TypeError(f"feature dtype {z.dtype} does not match the engine's compute dtype {self.dtype}")
+        if torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in head_params)):
+            outs = _TranslatorFn.apply(self, names, z, *head_params)
+        else:
+            outs, _ = self._translator_fwd(z, names, save=False)
+        return {t: o for t, o in zip(names, outs)}
+
+    def _head(self, t: str):
+        tr = self.rvfm.translator
+        return tr.translator_heads[tr.legit_target_model_name_map[t]]
+
+    def _conv_fwd(self, x, wf, bias, plan, b, out, relu: bool):
+        C = self.D
+        for rmap, mpi in plan.fwd:
+            ops.gemm_nt(x, wf, out, b * mpi, C, rmap.ntaps * C, rmap, 9 * C, C, bias=bias, act=N.ACT_RELU if relu else N.ACT_NONE)
+        return out
+
+    def _translator_fwd(self, z: torch.Tensor, names: List[str], save: bool):
+        dev, T, C = z.device, self.dtype, self.D
+        oc = self._operands(dev)
+        b = z.shape[0]
+        z = z.contiguous()
+        outs, saved = [], []
+        for t in names:
+            hm = self._head(t)
+            pf = f"h:{t}."
+            s0, s1, s2 = hm.sizes
+            chw_ws = self.ws(N.lib().theia_layernorm_chw_workspace_bytes(b, s2 * s2 * C) // 4, dev)
+            u1 = torch.empty(b, 256 * C, dtype=T, device=dev)
+            self._conv_fwd(z, oc[pf + "pad.wf"], hm.pad["1"].bias, self._plan("pad"), b, u1, relu=False)
+            v1, st0 = ops.layernorm_chw_fwd(u1, oc[pf + "ln0.g"], oc[pf + "ln0.b"], LN_EPS_HEAD, chw_ws)
+            p1, p4 = ("up31", "up64") if hm.kind == "up64" else ("conv16", "conv16")
+            u2 = torch.empty(b, s1 * s1 * C, dtype=T, device=dev)
+            self._conv_fwd(v1, oc[pf + "c1.wf"], hm.adapter["1"].bias, self._plan(p1), b, u2, relu=True)
+            v2, st3 = ops.layernorm_chw_fwd(u2, oc[pf + "ln3.g"], oc[pf + "ln3.b"], LN_EPS_HEAD, chw_ws)
+            u3 = torch.empty(b, s2 * s2 * C, dtype=T, device=dev)
+            self._conv_fwd(v2, oc[pf + "c4.wf"], hm.adapter["4"].bias, self._plan(p4), b, u3, relu=True)
+            v3, st6 = ops.layernorm_chw_fwd(u3, oc[pf + "ln6.g"], oc[pf + "ln6.b"], LN_EPS_HEAD, chw_ws)
+            pred = ops.linear(v3.view(b * s2 * s2, C), oc[pf + "w8"], hm.adapter["8"].bias)
+            outs.append(pred.view(b, s2 * s2, -1))
+            if save:
+                saved.append((u1, st0, v1, u2, st3, v2, u3, st6, v3))
+        return tuple(outs), {"z": z if save else None, "heads": saved, "b": b}
+
+    def _translator_bwd(self, saved, names: List[str], dpreds: Sequence[Optional[torch.Tensor]]) -> torch.Tensor:
+        z = saved["z"]
+        dev, T, C, b = z.device, self.dtype, self.D, saved["b"]
+        oc = self._operands(dev)
+        dz = torch.zeros(b, NTOK, C, dtype=T, device=dev)
+        for hi, t in enumerate(names):
+            dp = dpreds[hi]
+            hm = self._head(t)
+            bucket = self._bucket_of[id(hm.adapter["8"].weight)][0]
+            if dp is None:
+                continue
+            train = hm.adapter["8"].weight.requires_grad
+            pf = f"h:{t}."
+            (u1, st0, v1, u2, st3, v2, u3, st6, v3) = saved["heads"][hi]
+            saved["heads"][hi] = None
+            s0, s1, s2 = hm.sizes
+            Ct = dp.shape[-1]
+            E3 = s2 * s2 * C
+            chw_need = N.lib().theia_layernorm_chw_workspace_bytes(b, E3) // 4
+            conv_slabs = max(ops.wgrad_splits(b * hw * hw, C, 9 * C) for hw in (16, s1, s2)) * 9 * C * C
+            lin_slabs = ops.wgrad_splits(b * s2 * s2, Ct, C) * Ct * C
+            ws = self.ws(max(chw_need + 2 * E3 + 64, conv_slabs, lin_slabs,
+                             N.lib().theia_colsum_workspace_bytes(b * s2 * s2, max(C, Ct)) // 4 + 64), dev)
+            dp = dp.contiguous().view(b * s2 * s2, Ct)
+            if dp.dtype != T:
+                raise TypeError(f"gradient dtype {dp.dtype} does not match the engine's compute dtype {T}")
+
+            def lin_grads(dy, x, mod):
+                if not train:
+                    return
+                g, acc = self._grad(mod.weight)
+                ops.linear_wgrad(dy, x, g, acc, ws)
+                g, acc = self._grad(mod.bias)
+                ops.colsum(dy, g, acc, ws)
+
+            def conv_grads(dy2d, x, mod, plan, mtot):
+                """dy2d [M_total, C] is the conv output gradient, x the conv input (flat NHWC)."""
+                if not train:
+                    return
+                g, acc = self._grad(mod.bias)
+                ops.colsum(dy2d, g, acc, ws)
+                g, acc = self._grad(mod.weight)
+                splits = ops.wgrad_splits(mtot, C, 9 * C)
+                slabs = ws[: splits * C * 9 * C]
+                for rmap, mpi in plan.fwd:
+                    ops.gemm_wgrad(dy2d, x, slabs, b * mpi, C, C, 9, splits, rmap)
+                sn, ss, sc = plan.grad_strides
+                ops.wgrad_reduce(slabs, splits, C, 9, C, g, sn, ss, sc, acc)
+
+            def ln_bwd(dy, x, stats, idx, hw, relu_mask):
+                E = hw * hw * C
+                tmp_g = ws[chw_need: chw_need + E]
+                tmp_b = ws[chw_need + E3: chw_need + E3 + E]
+                dx = ops.layernorm_chw_bwd(dy, x, oc[pf + f"ln{idx}.g"], stats, tmp_g, tmp_b, relu_mask, False, ws[:chw_need])
+                if train:
+                    g, acc = self._grad(hm.adapter[idx].weight)
+                    ops.unpermute3(tmp_g, g, hw * hw, 1, C, 1, 0, hw * hw, acc)
+                    g, acc = self._grad(hm.adapter[idx].bias)
+                    ops.unpermute3(tmp_b, g, hw * hw, 1, C, 1, 0, hw * hw, acc)
+                return dx
+
+            def conv_dgrad(dy, wd, plan, out, resid=None):
+                rmap, mpi = plan.dgrad
+                ops.gemm_nt(dy, wd, out, b * mpi, C, 9 * C, rmap, 9 * C, C, resid=resid)
+                return out
+
+            p1, p4 = ("up31", "up64") if hm.kind == "up64" else ("conv16", "conv16")
+            lin_grads(dp, v3.view(b * s2 * s2, C), hm.adapter["8"])
+            dv3 = ops.linear(dp, oc[pf + "w8T"])
+            del v3
+            du3 = ln_bwd(dv3.view(b, E3), u3, st6, "6", s2, True)
+            del dv3, u3
+            conv_grads(du3.view(b * s2 * s2, C), v2, hm.adapter["4"], self._plan(p4), b * s2 * s2)
+            dv2 = conv_dgrad(du3, oc[pf + "c4.wd"], self._plan(p4), torch.empty(b, s1 * s1 * C, dtype=T, device=dev))
+            del du3, v2
+            du2 = ln_bwd(dv2, u2, st3, "3", s1, True)
+            del dv2, u2
+            conv_grads(du2.view(b * s1 * s1, C), v1, hm.adapter["1"], self._plan(p1), b * s1 * s1)
+            dv1 = conv_dgrad(du2, oc[pf + "c1.wd"], self._plan(p1), torch.empty(b, 256 * C, dtype=T, device=dev))
+            del du2, v1
+            du1 = ln_bwd(dv1, u1, st0, "0", s0, False)
+            del dv1, u1
+            conv_grads(du1.view(b * 256, C), z, hm.pad["1"], self._plan("pad"), b * 256)
+            conv_dgrad(du1, oc[pf + "pad.wd"], self._plan("pad"), dz, resid=dz)
+            del du1
+            if train:
+                self._bucket_done(bucket)
+        return dz
+
+    # ================================================================== loss
+    def distill_loss(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """-> f32[3] = (mse, cos, smooth_l1) of one teacher (models/rvfm.py:153-168)."""
+        if target.dtype != torch.float32:
+            raise TypeError("teacher features must be float32 (the reference feeds .float() tensors, train_rvfm.py:112-114)")
+        if pred.shape != target.shape:
+            raise ValueError(f"prediction {tuple(pred.shape)} and target {tuple(target.shape)} shapes differ")
+        target = target.to(pred.device).contiguous()
+        if torch.is_grad_enabled() and pred.requires_grad:
+            return _LossFn.apply(self, pred, target)
+        b = pred.shape[0]
+        losses, _ = ops.distill_loss_fwd(pred.contiguous().view(b, -1), target.view(b, -1),
+                                         self.ws(N.lib().theia_distill_loss_workspace_bytes(b, pred[0].numel()) // 4, pred.device))
+        return losses
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng: StudentEngine, img, channels_last, do_rescale, do_normalize, *params):
+        z, saved = eng._backbone_fwd(img, channels_last, do_rescale, do_normalize, save=True)
+        ctx.eng, ctx.saved, ctx.nparams = eng, saved, len(params)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        ctx.eng._backbone_bwd(ctx.saved, dz)
+        ctx.saved = None
+        return (None,) * (5 + ctx.nparams)
+
+
+class _TranslatorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng: StudentEngine, names, z, *params):
+        outs, saved = eng._translator_fwd(z, names, save=True)
+        ctx.eng, ctx.saved, ctx.names, ctx.nparams = eng, saved, names, len(params)
+        ctx.set_materialize_grads(False)  # heads whose prediction is unused get dpred = None and are skipped
+        return outs
+
+    @staticmethod
+    def backward(ctx, *dpreds):
+        dz = ctx.eng._translator_bwd(ctx.saved, ctx.names, dpreds)
+        ctx.saved = None
+        return (None, None, dz) + (None,) * ctx.nparams
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng: StudentEngine, pred, target):
+        b = pred.shape[0]
+        p2 = pred.contiguous().view(b, -1)
+        t2 = target.view(b, -1)
+        losses, coef = ops.distill_loss_fwd(p2, t2, eng.ws(N.lib().theia_distill_loss_workspace_bytes(b, p2.shape[1]) // 4, pred.device))
+        ctx.p2, ctx.t2, ctx.coef, ctx.shape = p2, t2, coef, pred.shape
+        return losses
+
+    @staticmethod
+    def backward(ctx, dl):
+        dp = ops.distill_loss_bwd(ctx.p2, ctx.t2, ctx.coef, dl.contiguous().float())
+        return None, dp.view(ctx.shape), None

@@ -1,0 +1,182 @@
+"""DeiT/ViT student backbone: parameter containers with the REFERENCE state_dict layout + the engine-backed forward.
+
+Mirrors the reference's ``models/backbones.py`` (``DeiT`` :255-341, ``build_backbone`` :506-526).  In the reference the
+arithmetic lives in HuggingFace ``ViTModel`` + the HF image processor; here the modules only HOLD the fp32 master
+parameters under the same names (``model.embeddings...``, ``model.layers.{i}...``, ``model.layernorm``) and every
+forward/backward runs in the HIP kernels driven by ``theia_amd.engine``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Optional
+
+import torch
+import torch.nn as nn
+
+# (hidden D, heads, mlp F) -- HF ViTConfig of facebook/deit-{tiny,small,base}-patch16-224; other fields are ViTConfig
+# defaults (12 layers, patch 16, image 224, layer_norm_eps 1e-12, erf GELU, qkv_bias) -- SURVEY.md sec. 8(c).
+ARCH = {
+    "facebook/deit-tiny-patch16-224": (192, 3, 768),
+    "facebook/deit-small-patch16-224": (384, 6, 1536),
+    "facebook/deit-base-patch16-224": (768, 12, 3072),
+}
+NUM_LAYERS = 12
+PATCH = 16
+IMAGE = 224
+GRID = 14
+NTOK = 197
+INIT_RANGE = 0.02  # ViTConfig.initializer_range
+
+
+class _Holder(nn.Module):
+    """A module that only owns parameters; calling it is a bug (compute lives in the engine)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError(f"{type(self).__name__} holds parameters only; use the owning model's forward")
+
+
+class LinearParams(_Holder):
+    def __init__(self, in_features: int, out_features: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+
+
+class LayerNormParams(_Holder):
+    def __init__(self, shape):
+        super().__init__()
+        shape = tuple(shape) if isinstance(shape, (tuple, list, torch.Size)) else (shape,)
+        self.weight = nn.Parameter(torch.ones(shape))
+        self.bias = nn.Parameter(torch.zeros(shape))
+
+
+class ConvParams(_Holder):
+    """weight in PyTorch layout: Conv2d [co, ci, kh, kw]; ConvTranspose2d [ci, co, kh, kw]."""
+
+    def __init__(self, weight_shape, bias_size: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*weight_shape))
+        self.bias = nn.Parameter(torch.empty(bias_size))
+
+
+class _PatchEmbeddings(_Holder):
+    def __init__(self, D: int):
+        super().__init__()
+        self.projection = ConvParams((D, 3, PATCH, PATCH), D)
+
+
+class _Embeddings(_Holder):
+    def __init__(self, D: int):
+        super().__init__()
+        self.cls_token = nn.Parameter(torch.empty(1, 1, D))
+        self.position_embeddings = nn.Parameter(torch.empty(1, NTOK, D))
+        self.patch_embeddings = _PatchEmbeddings(D)
+
+
+class _Attention(_Holder):
+    def __init__(self, D: int):
+        super().__init__()
+        self.q_proj = LinearParams(D, D)
+        self.k_proj = LinearParams(D, D)
+        self.v_proj = LinearParams(D, D)
+        self.o_proj = LinearParams(D, D)
+
+
+class _MLP(_Holder):
+    def __init__(self, D: int, F: int):
+        super().__init__()
+        self.fc1 = LinearParams(D, F)
+        self.fc2 = LinearParams(F, D)
+
+
+class _Layer(_Holder):
+    def __init__(self, D: int, F: int):
+        super().__init__()
+        self.attention = _Attention(D)
+        self.layernorm_before = LayerNormParams(D)
+        self.layernorm_after = LayerNormParams(D)
+        self.mlp = _MLP(D, F)
+
+
+class ViTParams(_Holder):
+    """Same parameter names as HF ``ViTModel`` (pooler removed: the reference sets it to Identity, backbones.py:283)."""
+
+    def __init__(self, D: int, heads: int, F: int):
+        super().__init__()
+        self.hidden_size, self.num_heads, self.intermediate_size = D, heads, F
+        self.embeddings = _Embeddings(D)
+        self.layers = nn.ModuleList([_Layer(D, F) for _ in range(NUM_LAYERS)])
+        self.layernorm = LayerNormParams(D)
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self) -> None:
+        """HF ViT ``_init_weights``: trunc-normal(std 0.02) matrices / pos-emb / cls, zero biases, unit LayerNorm."""
+        for name, p in self.named_parameters():
+            if "layernorm" in name:
+                (nn.init.ones_ if name.endswith("weight") else nn.init.zeros_)(p)
+            elif name.endswith("bias"):
+                nn.init.zeros_(p)
+            else:
+                nn.init.trunc_normal_(p, mean=0.0, std=INIT_RANGE)
+
+
+# reference-era (transformers 4.4x) checkpoint key -> current key  (not verifiable offline)
+def remap_legacy_key(k: str) -> str:
+    k = k.replace(".encoder.layer.", ".layers.")
+    k = k.replace(".attention.attention.query.", ".attention.q_proj.")
+    k = k.replace(".attention.attention.key.", ".attention.k_proj.")
+    k = k.replace(".attention.attention.value.", ".attention.v_proj.")
+    k = k.replace(".attention.output.dense.", ".attention.o_proj.")
+    k = k.replace(".intermediate.dense.", ".mlp.fc1.")
+    if ".layers." in k and ".output.dense." in k:
+        k = k.replace(".output.dense.", ".mlp.fc2.")
+    return k
+
+
+class DeiT(nn.Module):
+    """DeiT student (reference ``DeiT`` backbones.py:255-341).  ``forward`` takes uint8 images and returns the last
+    hidden state [B, 197, D]; image preprocessing (rescale + normalise) is fused into the ingest kernel."""
+
+    def __init__(self, model_name: str = "facebook/deit-small-patch16-224", pretrained: bool = False, image_size: int = 224):
+        super().__init__()
+        if model_name not in ARCH:
+            raise NotImplementedError(f"Requested {model_name} is not implemented.")
+        if pretrained:
+            raise NotImplementedError("pretrained HF weights cannot be fetched offline; load a checkpoint with "
+                                      "RobotVisionFM.load_pretrained_weights instead")
+        self.model_name = model_name
+        self.image_size = image_size
+        D, heads, F = ARCH[model_name]
+        self.model = ViTParams(D, heads, F)
+        # explicit processor configuration: 224, no crop, ImageNet mean/std
+        self.image_mean = (0.485, 0.456, 0.406)
+        self.image_std = (0.229, 0.224, 0.225)
+        self._engine = None  # set by RobotVisionFM
+
+    def get_feature_size(self, keep_spatial: bool = False, return_torch_size: bool = False):
+        D = self.model.hidden_size
+        size = (D, GRID * GRID)
+        if keep_spatial:
+            assert math.isqrt(size[-1])
+            size = (D, GRID, GRID)
+            if return_torch_size:
+                size = torch.Size(size)
+        return size
+
+    def forward(self, x: Any, do_resize: bool = True, interpolate_pos_encoding: Optional[bool] = None, do_rescale: bool = True,
+                do_normalize: bool = True) -> torch.Tensor:
+        if self._engine is None:
+            raise RuntimeError("DeiT is driven by RobotVisionFM's engine; construct it through RobotVisionFM")
+        if interpolate_pos_encoding:
+            raise NotImplementedError("interpolate_pos_encoding is outside the round-1 hot path (SURVEY.md sec. 8f-3)")
+        return self._engine.backbone(x, do_rescale=do_rescale, do_normalize=do_normalize)
+
+
+def build_backbone(model_name: str, pretrained: bool = False, image_size: int = 224, **kwargs: Any) -> nn.Module:
+    """Reference ``build_backbone`` backbones.py:506-526 (reg-/nocls- variants are "next")."""
+    if "reg" in model_name or "nocls" in model_name:
+        raise NotImplementedError(f"{model_name}: register-token / no-CLS variants are not part of the hot path yet")
+    if "deit" in model_name:
+        return DeiT(model_name=model_name, pretrained=pretrained, image_size=image_size)
+    raise NotImplementedError(f"Requested {model_name} is not implemented.")

@@ -1,0 +1,46 @@
+"""``lconv`` feature translator (reference models/feature_translators.py:12-88,159-205,293-313).
+
+backbone_adapter = Identity and translator_stem = Identity for ``lconv`` (feature_translators.py:56,183), so the
+translator is just the per-teacher heads; head module names are the teacher names with '.' -> '_' (:46)."""
+from __future__ import annotations
+
+from typing import Any, Optional
+
+import torch
+import torch.nn as nn
+
+from .adapter_heads import LightConvAdapterHead
+
+
+class LightConvFeatureTranslator(nn.Module):
+    def __init__(self, backbone_feature_size, target_feature_sizes: dict, translator_hidden_size: int = 1024,
+                 hidden_size_factor: float = 1.0) -> None:
+        super().__init__()
+        self.backbone_feature_size = backbone_feature_size
+        self.target_feature_sizes = target_feature_sizes
+        self.translator_hidden_size = translator_hidden_size
+        self.hidden_size_factor = hidden_size_factor
+        self.target_model_names = list(target_feature_sizes.keys())
+        self.legit_target_model_name_map = {t: t.replace(".", "_") for t in self.target_model_names}
+        heads = {}
+        for t, size in target_feature_sizes.items():
+            if "_cls" in t:
+                raise NotImplementedError("CLS-token distillation heads are outside the round-1 hot path (SURVEY.md sec. 8f-5)")
+            heads[self.legit_target_model_name_map[t]] = LightConvAdapterHead(backbone_feature_size, size, hidden_size_factor)
+        self.translator_heads = nn.ModuleDict(heads)
+        self._engine = None  # set by RobotVisionFM
+
+    def forward(self, x: torch.Tensor, target_model_names: Optional[list] = None, backbone_no_cls: bool = False) -> dict:
+        if self._engine is None:
+            raise RuntimeError("the translator is driven by RobotVisionFM's engine")
+        assert not backbone_no_cls, "DeiT backbone always carries a CLS token"
+        names = target_model_names if target_model_names is not None else self.target_model_names
+        return self._engine.translator(x, list(names))
+
+
+def build_feature_translator(translator_type: str, **kwargs: Any) -> nn.Module:
+    if translator_type == "lconv":
+        return LightConvFeatureTranslator(**kwargs)
+    if translator_type in ("mlp", "conv", "transformer", "trans"):
+        raise NotImplementedError(f"translator '{translator_type}' is out of the hot-path scope (only 'lconv', the reference default)")
+    raise NotImplementedError(f"Requested {translator_type} is not implemented yet.")
