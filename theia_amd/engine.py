@@ -83,14 +83,24 @@ def to_uint8_batch(x: Any) -> Tuple[torch.Tensor, bool]:
 class GradBucket:
     """A flat fp32 gradient buffer for a group of parameters, filled in backward-completion order."""
 
-    def __init__(self, name: str, params: List[torch.nn.Parameter]):
+    def __init__(self, name: str, named_params: List[Tuple[str, torch.nn.Parameter]]):
+        from .optimizers.utils import is_no_decay
         self.name = name
-        self.params = params
+        # [weight-decayed params | no-decay params] so a fused optimizer needs two launches per bucket
+        decay = [(n, p) for n, p in named_params if not is_no_decay(n, p)]
+        nodecay = [(n, p) for n, p in named_params if is_no_decay(n, p)]
+        self.names = [n for n, _ in decay + nodecay]
+        self.params = [p for _, p in decay + nodecay]
         self.offsets: List[int] = []
         off = 0
-        for p in params:
+        self.decay_numel = 0
+        for i, p in enumerate(self.params):
+            if i == len(decay):
+                self.decay_numel = off
             self.offsets.append(off)
             off += (p.numel() + 7) // 8 * 8  # keep every view 32-byte aligned for vector stores
+        if len(nodecay) == 0:
+            self.decay_numel = off
         self.numel = off
         self.flat: Optional[torch.Tensor] = None
 
@@ -133,18 +143,20 @@ class StudentEngine:
     def _build_buckets(self) -> None:
         """Backward-completion order: heads (in forward order), then backbone layer groups from the top down."""
         self.buckets = []
+        tr = getattr(self.rvfm, "translator", None)
         for t, hm in self.head_modules():
-            self.buckets.append(GradBucket(f"head:{t}", list(hm.parameters())))
+            pre = f"translator.translator_heads.{tr.legit_target_model_name_map[t]}."
+            self.buckets.append(GradBucket(f"head:{t}", [(pre + n, p) for n, p in hm.named_parameters()]))
         vit = self.rvfm.backbone.model
         groups = [(9, 12), (6, 9), (3, 6), (0, 3)]
         for gi, (lo, hi) in enumerate(groups):
-            ps: List[torch.nn.Parameter] = []
+            ps: List[Tuple[str, torch.nn.Parameter]] = []
             if gi == 0:
-                ps += list(vit.layernorm.parameters())
+                ps += [("backbone.model.layernorm." + n, p) for n, p in vit.layernorm.named_parameters()]
             for li in range(hi - 1, lo - 1, -1):
-                ps += list(vit.layers[li].parameters())
+                ps += [(f"backbone.model.layers.{li}." + n, p) for n, p in vit.layers[li].named_parameters()]
             if lo == 0:
-                ps += list(vit.embeddings.parameters())
+                ps += [("backbone.model.embeddings." + n, p) for n, p in vit.embeddings.named_parameters()]
             self.buckets.append(GradBucket(f"vit:{lo}-{hi - 1}", ps))
         self._bucket_of = {}
         for b in self.buckets:

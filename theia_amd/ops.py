@@ -105,6 +105,10 @@ def _dt(t: torch.Tensor) -> int:
     return N.dtype_code(t.dtype)
 
 
+# when set to a list, gemm_nt appends (start_event, end_event, algorithmic_flops, tile_variant, (M, N, K)) per launch
+GEMM_PROFILE: Optional[list] = None
+
+
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int, K: int, rmap: RowMap, ldw: int, ldo: int,
             bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, act: int = N.ACT_NONE,
             aux_in: Optional[torch.Tensor] = None, aux_out: Optional[torch.Tensor] = None,
@@ -116,6 +120,14 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int
     g.M, g.N, g.K, g.ldw, g.ldo, g.act = M, Nn, K, ldw, ldo, act
     g.map = rmap
     assert a.dtype == w.dtype == out.dtype
+    if GEMM_PROFILE is not None:  # bench.py: HIP events on the launch stream around every theia_gemm_nt launch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        N.check(N.lib().theia_gemm_nt(g, _dt(a), N.stream_ptr()), "theia_gemm_nt")
+        e1.record()
+        t128 = (Nn + 127) // 128 * 128
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * Nn * K, "128x64" if (t128 - Nn) * 8 > t128 else "128x128", (M, Nn, K)))
+        return out
     N.check(N.lib().theia_gemm_nt(g, _dt(a), N.stream_ptr()), "theia_gemm_nt")
     return out
 
