@@ -1,0 +1,150 @@
+"""CPU: the C-ABI library loads and exports every symbol include/theia_hip.h declares; argument validation of the
+entry points (no GPU work is launched); host-side logic (row maps, buckets, decay rule, input handling)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "theia_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(theia_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from theia_amd import _native as N
+    lib = N.lib()
+    declared = header_functions()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/theia_hip.h but not exported"
+    assert sorted(N.EXPORTED_SYMBOLS) == declared, "ctypes signature table and header disagree"
+    assert lib.theia_abi_version() == 1
+    assert lib.theia_dtype_size(N.F32) == 4 and lib.theia_dtype_size(N.BF16) == 2 and lib.theia_dtype_size(7) == -1
+
+
+def test_struct_layout_matches_header():
+    from theia_amd import _native as N
+    # theia_rowmap_t: 1 + 27 + 2 + 2 + 2 + 1 + 5 int32 = 40 int32 (160 B) then 4 int64
+    assert C.sizeof(N.RowMap) == 160 + 32
+    assert N.RowMap.in_batch_stride.offset == 160
+    assert C.sizeof(N.GemmArgs) == 8 * 8 + 4 * 7 + 4 + C.sizeof(N.RowMap)  # 8 pointers, 7 int32 + pad, map
+
+
+def test_argument_validation_errors_without_gpu():
+    from theia_amd import _native as N
+    lib = N.lib()
+    g = N.GemmArgs()
+    assert lib.theia_gemm_nt(g, N.BF16, None) == -1
+    assert b"null operand" in lib.theia_last_error()
+    g.a = g.w = g.out = 4096
+    g.M, g.N, g.K = 8, 12, 64
+    assert lib.theia_gemm_nt(g, N.BF16, None) == -1 and b"multiple of 8" in lib.theia_last_error()
+    assert lib.theia_gemm_nt(g, 5, None) == -1 and b"dtype" in lib.theia_last_error()
+    assert lib.theia_layernorm_fwd(4096, 4096, 4096, 4096, 4096, 4096, 4, 100, 1e-12, N.F32, None) == -1
+    assert lib.theia_attention_fwd(4096, 4096, 4096, 1, 300, 3, N.F32, None) == -1 and b"n=300" in lib.theia_last_error()
+    assert lib.theia_distill_loss_fwd(4096, 4096, 4096, 4096, 4096, 2, 12, N.F32, None) == -1
+    w = N.WgradArgs()
+    assert lib.theia_gemm_wgrad(w, N.BF16, None) == -1
+    assert lib.theia_wgrad_splits(25216, 768, 768) >= 1
+    with pytest.raises(N.TheiaNativeError):
+        N.check(-1, "x")
+
+
+def test_convT_parity_classes_cover_output_exactly_once():
+    from theia_amd import ops
+    for IH, s, p, op in ((16, 2, 1, 0), (31, 2, 0, 1), (14, 1, 0, 0)):
+        plan = ops.plan_convT3x3(64, IH, s, p, op)
+        OH = plan.out_hw
+        hit = np.zeros((OH, OH), dtype=int)
+        taps_total = set()
+        for rmap, mpi in plan.fwd:
+            assert mpi == rmap.rows_h * rmap.rows_w
+            for ry in range(rmap.rows_h):
+                for rx in range(rmap.rows_w):
+                    hit[ry * rmap.out_sy + rmap.out_y0, rx * rmap.out_sx + rmap.out_x0] += 1
+            for t in range(rmap.ntaps):
+                assert rmap.wslot[t] not in taps_total
+                taps_total.add(rmap.wslot[t])
+        assert (hit == 1).all()
+        assert taps_total == set(range(9))
+        # cross-check tap geometry against the definition out[i*s - p + k] += in[i] * W[k]
+        for rmap, _ in plan.fwd:
+            for t in range(rmap.ntaps):
+                ky, kx = divmod(rmap.wslot[t], 3)
+                oy = rmap.out_y0 + 2 * rmap.out_sy if rmap.rows_h > 2 else rmap.out_y0
+                ry = (oy - rmap.out_y0) // rmap.out_sy
+                i = ry * rmap.in_sy + rmap.dy[t]
+                assert i * s - p + ky == oy
+
+
+def test_input_handling_matches_reference_contract():
+    from PIL import Image
+    from theia_amd.engine import preprocess_lut, to_uint8_batch
+    from oracle import theia_oracle as O
+    assert np.array_equal(preprocess_lut(True, True, O.IMAGENET_MEAN, O.IMAGENET_STD), O.preprocess_lut())
+    assert np.array_equal(preprocess_lut(False, False, O.IMAGENET_MEAN, O.IMAGENET_STD), np.tile(np.arange(256, dtype=np.float32), (3, 1)))
+    img = O.synth_images(2, 1)
+    t, cl = to_uint8_batch(img)
+    assert cl and t.shape == (2, 224, 224, 3)
+    t, cl = to_uint8_batch(img.permute(0, 3, 1, 2))
+    assert not cl and t.shape == (2, 3, 224, 224)
+    t, cl = to_uint8_batch([Image.fromarray(img[i].numpy()) for i in range(2)])
+    assert cl and torch.equal(t, img)
+    t, cl = to_uint8_batch(img[0].numpy())
+    assert t.shape == (1, 224, 224, 3)
+    with pytest.raises(TypeError):
+        to_uint8_batch(img.float())
+    with pytest.raises(NotImplementedError):
+        to_uint8_batch(torch.zeros(1, 256, 256, 3, dtype=torch.uint8))
+
+
+def test_model_state_dict_buckets_and_decay_rule():
+    from theia_amd.foundation_models.common import get_model_feature_size
+    from theia_amd.models.rvfm import RobotVisionFM
+    from theia_amd.optimizers import param_groups_weight_decay
+    from oracle import theia_oracle as O
+    bb, teachers = "facebook/deit-tiny-patch16-224", O.TEACHER_SETS["cddsv"]
+    m = RobotVisionFM(backbone=bb, translator="lconv", translator_kwargs={"hidden_size_factor": 1.0},
+                      target_feature_sizes={t: get_model_feature_size(t, keep_spatial=True) for t in teachers})
+    shapes = O.param_shapes(bb, teachers)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())  # same names AND registration order as the reference
+    for k, s in shapes.items():
+        assert tuple(sd[k].shape) == tuple(s), k
+    groups = param_groups_weight_decay(m, 0.01)
+    nodecay = {id(p) for p in groups[0]["params"]}
+    named = dict(m.named_parameters())
+    # reference quirk (optimizers/utils.py:30): cls/pos and the 3-D LayerNorm weights DO decay; every *.bias does not
+    assert id(named["backbone.model.embeddings.cls_token"]) not in nodecay
+    assert id(named["backbone.model.embeddings.position_embeddings"]) not in nodecay
+    k3 = "translator.translator_heads.facebook/sam-vit-huge.adapter.6."
+    assert id(named[k3 + "weight"]) not in nodecay and id(named[k3 + "bias"]) in nodecay
+    assert id(named["backbone.model.layernorm.weight"]) in nodecay
+    # buckets: every parameter exactly once, decayed ones first, 32-byte aligned views
+    seen = set()
+    for b in m.engine.buckets:
+        assert b.numel % 8 == 0 and all(o % 8 == 0 for o in b.offsets)
+        for i, (n, p) in enumerate(zip(b.names, b.params)):
+            assert id(p) not in seen
+            seen.add(id(p))
+            assert (b.offsets[i] < b.decay_numel) == (id(p) not in nodecay), n
+    assert seen == {id(p) for p in m.parameters()}
+    assert [b.name.split(":")[0] for b in m.engine.buckets] == ["head"] * 5 + ["vit"] * 4
+    with pytest.raises(RuntimeError):
+        m.forward_feature(O.synth_images(1))  # CPU model: the product path refuses, it never falls back
+
+
+def test_legacy_checkpoint_key_remap():
+    from theia_amd.models.backbones import remap_legacy_key
+    assert remap_legacy_key("backbone.model.encoder.layer.3.attention.attention.query.weight") == "backbone.model.layers.3.attention.q_proj.weight"
+    assert remap_legacy_key("backbone.model.encoder.layer.0.attention.output.dense.bias") == "backbone.model.layers.0.attention.o_proj.bias"
+    assert remap_legacy_key("backbone.model.encoder.layer.11.intermediate.dense.weight") == "backbone.model.layers.11.mlp.fc1.weight"
+    assert remap_legacy_key("backbone.model.encoder.layer.11.output.dense.weight") == "backbone.model.layers.11.mlp.fc2.weight"
+    assert remap_legacy_key("backbone.model.embeddings.cls_token") == "backbone.model.embeddings.cls_token"

@@ -9,6 +9,11 @@
 //   bwd dkv: per key row j  :  (same p, ds with roles swapped)  dv_j = sum_i p_ij do_i ; dk_j = sum_i ds_ij q_i
 #include "common.h"
 
+// bf16 matrix-core kernels (attention_mfma.hip); the kernels in this file are the exact-f32 path and the fallback
+int theia_attention_fwd_mfma(const void* qkv, void* o, float* lse, int b, int n, int h, hipStream_t s);
+int theia_attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* delta,
+                             int b, int n, int h, hipStream_t s);
+
 constexpr int AT_DH = 64;
 constexpr int AT_PITCH = 68;    // floats per LDS row
 constexpr int AT_MAXN = 256;
@@ -245,6 +250,7 @@ extern "C" int theia_attention_fwd(const void* qkv, void* o, float* lse, int b, 
     THEIA_CHECK_ARG(b > 0 && h > 0 && n > 0 && n <= AT_MAXN, "theia_attention_fwd: n=%d must be in [1,%d]", n, AT_MAXN);
     THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16, "theia_attention_fwd: bad dtype");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == THEIA_BF16 && n <= 208) return theia_attention_fwd_mfma(qkv, o, lse, b, n, h, s);  // matrix-core path
     const size_t lds = ((size_t)2 * n * AT_PITCH + AT_WAVES * (AT_DH + AT_MAXN)) * sizeof(float);
     const int ns = attn_nsplit(b * h, n);
     if (dtype == THEIA_BF16) {
@@ -264,7 +270,8 @@ extern "C" int theia_attention_bwd(const void* qkv, const void* o, const void* d
     THEIA_CHECK_ARG(b > 0 && h > 0 && n > 0 && n <= AT_MAXN, "theia_attention_bwd: n=%d must be in [1,%d]", n, AT_MAXN);
     THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16, "theia_attention_bwd: bad dtype");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const size_t lds1 = ((size_t)2 * n * AT_PITCH + AT_WAVES * (2 * AT_DH + AT_MAXN)) * sizeof(float);
+    if (dtype == THEIA_BF16 && n <= 208) return theia_attention_bwd_mfma(qkv, o, d_o, lse, dqkv, delta_ws, b, n, h, s);
+    const size_t lds1 =((size_t)2 * n * AT_PITCH + AT_WAVES * (2 * AT_DH + AT_MAXN)) * sizeof(float);
     const size_t lds2 = ((size_t)2 * n * AT_PITCH + AT_WAVES * (2 * AT_DH + 2 * AT_MAXN)) * sizeof(float);
     const int ns = attn_nsplit(b * h, n);
     if (dtype == THEIA_BF16) {

@@ -1,0 +1,319 @@
+// K4 (bf16 throughput path): multi-head self-attention forward / backward on the matrix cores.
+//
+// One workgroup (4 wave64) per (image, head); head_dim = 64; n <= 208 tokens (197 for DeiT), processed as 13 tiles of
+// 16 query (resp. key) rows distributed round-robin over the waves.  The head's K,V (fwd, dQ) or Q,dO (dK/dV) live in
+// LDS as natural [token][64] bf16 rows of pitch 144 B:
+//   * "natural" operand fragments (16 rows x 8 consecutive d) are ds_read_b128 -- pitch 144 = 9*16 B makes the 16 rows
+//     of a fragment hit 16 different 16-byte bank slots;
+//   * "transposed" operand fragments (16 d-columns x 8 tokens) come from the SAME image through ds_read_b64_tr_b16.
+// v_mfma_f32_16x16x32_bf16 everywhere.  The score tile is computed transposed (A = K rows, B = Q rows) so a lane owns
+// ONE query row and 4 consecutive keys per 16-key tile: the softmax row reductions are lane-local + 2 shuffles, and
+// P (resp. dS) feeds the next MFMA as its B operand straight from registers: two 16-key accumulator tiles are packed
+// into one K=32 fragment whose k-slots are permuted as  slot(g, j<4) = 32s + 4g + j,  slot(g, j>=4) = 32s + 16 + 4g +
+// (j-4);  the A operand (V^T / K^T / dO^T / Q^T via the transposing LDS read) uses the same permutation, so the
+// contraction is unchanged.  Softmax statistics and all accumulation are f32.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 am_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float am_f32x4;
+typedef __attribute__((ext_vector_type(4))) short am_s16x4;
+
+constexpr int AM_PITCH = 144;   // bytes per LDS token row (64 bf16 + 16 B pad)
+constexpr int AM_TILES = 13;    // 16-row tiles covering n <= 208
+constexpr int AM_ROWS = 224;    // token rows kept in LDS (7 k-steps of 32)
+constexpr int AM_KSTEPS = 7;
+
+__device__ __forceinline__ void am_mma(am_f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(am_bf16x8, a), __builtin_bit_cast(am_bf16x8, b), acc, 0, 0, 0);
+}
+
+// stage `rows` token rows (zero beyond n) of a [token][64] bf16 matrix with the given global row stride
+__device__ __forceinline__ void am_stage(const bf16_t* __restrict__ src, int64_t row_stride, int n, int rows, char* __restrict__ dst) {
+    for (int v = threadIdx.x; v < rows * 8; v += blockDim.x) {
+        const int r = v >> 3, c = v & 7;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (r < n) x = *reinterpret_cast<const uint4*>(src + r * row_stride + c * 8);
+        *reinterpret_cast<uint4*>(dst + r * AM_PITCH + c * 16) = x;
+    }
+}
+
+// natural fragment: row (row0 + lane&15), d = kk*32 + (lane>>4)*8 .. +8
+__device__ __forceinline__ uint4 am_nat(const char* __restrict__ base, int row0, int kk, int lane) {
+    return *reinterpret_cast<const uint4*>(base + (row0 + (lane & 15)) * AM_PITCH + (kk * 4 + (lane >> 4)) * 16);
+}
+
+// transposed fragment: column d = df*16 + (lane&15); tokens 32s + 4g + {0..3} and 32s + 16 + 4g + {0..3}
+__device__ __forceinline__ uint4 am_tr(const char* __restrict__ base, int s, int df, int lane) {
+    const int q = lane & 15, g = lane >> 4;
+    const char* p = base + (s * 32 + g * 4 + (q >> 2)) * AM_PITCH + (df * 16 + (q & 3) * 4) * 2;
+    const am_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) am_s16x4*)(p));
+    const am_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) am_s16x4*)(p + 16 * AM_PITCH));
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+
+__device__ __forceinline__ uint32_t am_pack2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+__device__ __forceinline__ uint4 am_pack(const am_f32x4& t0, const am_f32x4& t1) {
+    return make_uint4(am_pack2(t0[0], t0[1]), am_pack2(t0[2], t0[3]), am_pack2(t1[0], t1[1]), am_pack2(t1[2], t1[3]));
+}
+__device__ __forceinline__ float am_rsum(float v) {  // sum over the 4 lane groups (lanes l, l^16, l^32, l^48)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float am_rmax(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+__device__ __forceinline__ void am_store4(bf16_t* p, const am_f32x4& v, float scale) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(am_pack2(v[0] * scale, v[1] * scale), am_pack2(v[2] * scale, v[3] * scale));
+}
+
+// ================================================================================================ forward
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                            float* __restrict__ lse, int n, int h) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    char* sK = sm;                          // [208][144]
+    char* sV = sm + 208 * AM_PITCH;         // [224][144]
+    const int bh = blockIdx.x, bi = bh / h, hi = bh % h;
+    const int D = h * 64;
+    const int64_t rs = 3 * (int64_t)D;
+    const bf16_t* base = qkv + (int64_t)bi * n * rs + hi * 64;
+    am_stage(base + D, rs, n, 208, sK);
+    am_stage(base + 2 * D, rs, n, AM_ROWS, sV);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q16 = lane & 15, g = lane >> 4;
+    for (int qt = wave; qt < AM_TILES; qt += 4) {
+        const int qrow = qt * 16 + q16;
+        uint4 qf[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            qf[kk] = make_uint4(0, 0, 0, 0);
+            if (qrow < n) qf[kk] = *reinterpret_cast<const uint4*>(base + qrow * rs + kk * 32 + g * 8);
+        }
+        am_f32x4 s[AM_TILES + 1];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < AM_TILES; ++kt) {
+            am_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            am_mma(acc, am_nat(sK, kt * 16, 0, lane), qf[0]);
+            am_mma(acc, am_nat(sK, kt * 16, 1, lane), qf[1]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + g * 4 + r;
+                acc[r] = key < n ? acc[r] * 0.125f : -INFINITY;
+                mx = fmaxf(mx, acc[r]);
+            }
+            s[kt] = acc;
+        }
+        mx = am_rmax(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < AM_TILES; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(s[kt][r] - mx);
+                s[kt][r] = p;
+                sum += p;
+            }
+        s[AM_TILES] = (am_f32x4){0.f, 0.f, 0.f, 0.f};
+        sum = am_rsum(sum);
+        am_f32x4 oa[4];
+#pragma unroll
+        for (int df = 0; df < 4; ++df) oa[df] = (am_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < AM_KSTEPS; ++ks) {
+            const uint4 pb = am_pack(s[2 * ks], s[2 * ks + 1]);
+#pragma unroll
+            for (int df = 0; df < 4; ++df) am_mma(oa[df], am_tr(sV, ks, df, lane), pb);
+        }
+        if (qrow < n) {
+            const float inv = 1.0f / sum;
+            bf16_t* orow = o + ((int64_t)bi * n + qrow) * D + hi * 64 + g * 4;
+#pragma unroll
+            for (int df = 0; df < 4; ++df) am_store4(orow + df * 16, oa[df], inv);
+            if (g == 0) lse[(int64_t)bh * n + qrow] = mx + __logf(sum);
+        }
+    }
+}
+
+// ================================================================================================ backward: dQ (+ delta)
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                               const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                               bf16_t* __restrict__ dqkv, float* __restrict__ delta, int n, int h) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    char* sK = sm;                          // [224][144] (also read transposed)
+    char* sV = sm + AM_ROWS * AM_PITCH;     // [208][144]
+    const int bh = blockIdx.x, bi = bh / h, hi = bh % h;
+    const int D = h * 64;
+    const int64_t rs = 3 * (int64_t)D;
+    const bf16_t* base = qkv + (int64_t)bi * n * rs + hi * 64;
+    am_stage(base + D, rs, n, AM_ROWS, sK);
+    am_stage(base + 2 * D, rs, n, 208, sV);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q16 = lane & 15, g = lane >> 4;
+    for (int qt = wave; qt < AM_TILES; qt += 4) {
+        const int qrow = qt * 16 + q16;
+        const bool qok = qrow < n;
+        const int64_t orow = ((int64_t)bi * n + qrow) * D + hi * 64;
+        uint4 qf[2], gf[2];
+        float dl = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            qf[kk] = gf[kk] = make_uint4(0, 0, 0, 0);
+            if (qok) {
+                qf[kk] = *reinterpret_cast<const uint4*>(base + qrow * rs + kk * 32 + g * 8);
+                gf[kk] = *reinterpret_cast<const uint4*>(d_o + orow + kk * 32 + g * 8);
+                float a8[8], b8[8];
+                load8(d_o + orow + kk * 32 + g * 8, a8);
+                load8(o + orow + kk * 32 + g * 8, b8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl += a8[j] * b8[j];
+            }
+        }
+        dl = am_rsum(dl);
+        const float lq = qok ? lse[(int64_t)bh * n + qrow] : 0.f;
+        am_f32x4 ds[AM_TILES + 1];
+#pragma unroll
+        for (int kt = 0; kt < AM_TILES; ++kt) {
+            am_f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            am_mma(st, am_nat(sK, kt * 16, 0, lane), qf[0]);
+            am_mma(st, am_nat(sK, kt * 16, 1, lane), qf[1]);
+            am_mma(dp, am_nat(sV, kt * 16, 0, lane), gf[0]);
+            am_mma(dp, am_nat(sV, kt * 16, 1, lane), gf[1]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + g * 4 + r;
+                const float p = key < n ? __expf(st[r] * 0.125f - lq) : 0.f;
+                st[r] = p * (dp[r] - dl) * 0.125f;
+            }
+            ds[kt] = st;
+        }
+        ds[AM_TILES] = (am_f32x4){0.f, 0.f, 0.f, 0.f};
+        am_f32x4 dq[4];
+#pragma unroll
+        for (int df = 0; df < 4; ++df) dq[df] = (am_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < AM_KSTEPS; ++ks) {
+            const uint4 sb = am_pack(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+            for (int df = 0; df < 4; ++df) am_mma(dq[df], am_tr(sK, ks, df, lane), sb);
+        }
+        if (qok) {
+            bf16_t* drow = dqkv + ((int64_t)bi * n + qrow) * rs + hi * 64 + g * 4;
+#pragma unroll
+            for (int df = 0; df < 4; ++df) am_store4(drow + df * 16, dq[df], 1.0f);
+            if (g == 0) delta[(int64_t)bh * n + qrow] = dl;
+        }
+    }
+}
+
+// ================================================================================================ backward: dK, dV
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                bf16_t* __restrict__ dqkv, int n, int h) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    char* sQ = sm;                                   // [224][144]
+    char* sG = sm + AM_ROWS * AM_PITCH;              // [224][144]  dO
+    float* sL = reinterpret_cast<float*>(sm + 2 * AM_ROWS * AM_PITCH);   // [224] lse (+inf beyond n)
+    float* sD = sL + AM_ROWS;                                            // [224] delta
+    const int bh = blockIdx.x, bi = bh / h, hi = bh % h;
+    const int D = h * 64;
+    const int64_t rs = 3 * (int64_t)D;
+    const bf16_t* base = qkv + (int64_t)bi * n * rs + hi * 64;
+    am_stage(base, rs, n, AM_ROWS, sQ);
+    am_stage(d_o + (int64_t)bi * n * D + hi * 64, (int64_t)D, n, AM_ROWS, sG);
+    for (int i = threadIdx.x; i < AM_ROWS; i += blockDim.x) {
+        sL[i] = i < n ? lse[(int64_t)bh * n + i] : INFINITY;
+        sD[i] = i < n ? delta[(int64_t)bh * n + i] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k16 = lane & 15, g = lane >> 4;
+    for (int kt = wave; kt < AM_TILES; kt += 4) {
+        const int krow = kt * 16 + k16;
+        const bool kok = krow < n;
+        uint4 kf[2], vf[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            kf[kk] = vf[kk] = make_uint4(0, 0, 0, 0);
+            if (kok) {
+                kf[kk] = *reinterpret_cast<const uint4*>(base + krow * rs + D + kk * 32 + g * 8);
+                vf[kk] = *reinterpret_cast<const uint4*>(base + krow * rs + 2 * D + kk * 32 + g * 8);
+            }
+        }
+        am_f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int df = 0; df < 4; ++df) dk[df] = dv[df] = (am_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int ks = 0; ks < AM_KSTEPS; ++ks) {
+            am_f32x4 p[2], dsv[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int q0 = (2 * ks + t) * 16;
+                am_f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+                am_mma(sa, am_nat(sQ, q0, 0, lane), kf[0]);
+                am_mma(sa, am_nat(sQ, q0, 1, lane), kf[1]);
+                am_mma(da, am_nat(sG, q0, 0, lane), vf[0]);
+                am_mma(da, am_nat(sG, q0, 1, lane), vf[1]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qi = q0 + g * 4 + r;
+                    const float pv = __expf(sa[r] * 0.125f - sL[qi]);
+                    p[t][r] = pv;
+                    dsv[t][r] = pv * (da[r] - sD[qi]) * 0.125f;
+                }
+            }
+            const uint4 pb = am_pack(p[0], p[1]), sb = am_pack(dsv[0], dsv[1]);
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
+                am_mma(dv[df], am_tr(sG, ks, df, lane), pb);
+                am_mma(dk[df], am_tr(sQ, ks, df, lane), sb);
+            }
+        }
+        if (kok) {
+            bf16_t* drow = dqkv + ((int64_t)bi * n + krow) * rs + hi * 64 + g * 4;
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
+                am_store4(drow + D + df * 16, dk[df], 1.0f);
+                am_store4(drow + 2 * D + df * 16, dv[df], 1.0f);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers (called from attention.hip)
+static void am_set_lds(const void* kern, int bytes) {
+    static const void* seen[8];
+    static int nseen = 0;
+    for (int i = 0; i < nseen; ++i)
+        if (seen[i] == kern) return;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (nseen < 8) seen[nseen++] = kern;
+}
+
+int theia_attention_fwd_mfma(const void* qkv, void* o, float* lse, int b, int n, int h, hipStream_t s) {
+    const int lds = (208 + AM_ROWS) * AM_PITCH;
+    am_set_lds(reinterpret_cast<const void*>(attn_fwd_mfma_kernel), lds);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(b * h), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, n, h);
+    THEIA_CHECK_LAUNCH("theia_attention_fwd(mfma)");
+    return THEIA_OK;
+}
+
+int theia_attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* delta,
+                             int b, int n, int h, hipStream_t s) {
+    const int lds1 = (AM_ROWS + 208) * AM_PITCH;
+    const int lds2 = 2 * AM_ROWS * AM_PITCH + 2 * AM_ROWS * (int)sizeof(float);
+    am_set_lds(reinterpret_cast<const void*>(attn_bwd_dq_mfma_kernel), lds1);
+    am_set_lds(reinterpret_cast<const void*>(attn_bwd_dkv_mfma_kernel), lds2);
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(b * h), dim3(256), lds1, s, (const bf16_t*)qkv, (const bf16_t*)o,
+                       (const bf16_t*)d_o, lse, (bf16_t*)dqkv, delta, n, h);
+    THEIA_CHECK_LAUNCH("theia_attention_bwd(dq mfma)");
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(b * h), dim3(256), lds2, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse,
+                       delta, (bf16_t*)dqkv, n, h);
+    THEIA_CHECK_LAUNCH("theia_attention_bwd(dkv mfma)");
+    return THEIA_OK;
+}

@@ -1,0 +1,238 @@
+"""Training entry point for the MI355X hot path -- drop-in for the reference's ``scripts/train/train_rvfm.py``.
+
+    torchrun --nproc_per_node=8 --nnodes 1 --rdzv_backend c10d --rdzv_endpoint 127.0.0.1:11111 \
+        -m theia_amd.scripts.train.train_rvfm training/target_models=cddsv dataset=synthetic \
+        model.backbone.backbone=facebook/deit-base-patch16-224 training.batch_size=128 precision=bf16
+
+Same structure as the reference (train_rvfm.py: ``main`` :332-345 -> ``ddp_main`` :221-329 -> ``train`` :38-208), same
+config tree / override syntax (Hydra is used when importable, otherwise ``theia_amd.utils.config.compose``), same
+step order: batch -> forward -> get_loss -> main loss select -> zero_grad -> backward (gradient all-reduce over RCCL
+overlapped with it) -> optional clip -> optimizer.step -> lr_scheduler.step -> log -> optional translator freeze ->
+checkpoint (model-only state_dict on rank 0).
+
+Deliberate differences (documented in DESIGN.md): one process per GPU with ``TheiaDataParallel`` instead of torch DDP;
+loss scalars stay on the device and are read back every ``logging.log_interval`` steps instead of ~3T+7 blocking
+``.item()`` per step; ``random_target_models > 0`` is rejected (in the reference it samples 2 teachers and would
+dead-lock DDP with find_unused_parameters=False, train_rvfm.py:102-103); the webdataset reader is out of scope
+ -- ``dataset=synthetic`` feeds synthetic batches of the right shapes.
+"""
+from __future__ import annotations
+
+import math
+import os
+import os.path as osp
+import sys
+import time
+from typing import Any, Iterator
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from theia_amd.foundation_models.common import MODEL_FEATURE_SIZES, get_model_feature_size
+from theia_amd.models.rvfm import RobotVisionFM
+from theia_amd.optimizers import FusedAdamW, param_groups_weight_decay
+from theia_amd.parallel import TheiaDataParallel
+from theia_amd.utils import config as cfglib
+from theia_amd.utils.seed import seed_everything
+
+
+class SyntheticFrames:
+    """Infinite iterator of synthetic batches in the reference's batch format
+    ({"image": uint8 [b,224,224,3], teacher: {"embedding": [b, HW, C]}}), generated on the device."""
+
+    def __init__(self, batch_size: int, target_model_names, device, seed: int, fixed: bool = False):
+        self.b, self.names, self.device = batch_size, list(target_model_names), device
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+        self.fixed, self._cached = fixed, None  # fixed: replay one batch (over-fitting sanity runs)
+
+    def __iter__(self) -> Iterator[dict]:
+        return self
+
+    def __next__(self) -> dict:
+        if self.fixed and self._cached is not None:
+            return self._cached
+        batch: dict[str, Any] = {"image": torch.randint(0, 256, (self.b, 224, 224, 3), dtype=torch.uint8, device=self.device,
+                                                        generator=self.gen)}
+        for t in self.names:
+            C, H, W = get_model_feature_size(t, keep_spatial=True)
+            batch[t] = {"embedding": torch.randn(self.b, H * W, C, device=self.device, generator=self.gen)}
+        self._cached = batch if self.fixed else None
+        return batch
+
+
+def select_main_loss(losses: dict, main_loss: str | None):
+    """train_rvfm.py:119-122"""
+    if main_loss == "mse" or main_loss is None:
+        return losses["mse_loss"]
+    if main_loss == "cos_l1":
+        return 0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]
+    raise ValueError(f"unknown training.main_loss '{main_loss}'")
+
+
+def train(rvfm: nn.Module, target_model_names, optimizer, lr_scheduler, train_iter, eval_iter, cfg, device: int = 0,
+          train_epoch_steps: int = 0, eval_epoch_steps: int = 0, total_train_steps: int = 0, warmup_steps: int = 0) -> dict:
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    log_interval = int(cfg.logging.get("log_interval", 10))
+    steps = 0
+    history = {"train_main_loss": [], "eval_main_loss": []}
+    for ep in range(cfg.training.epochs):
+        rvfm.train()
+        t0 = time.time()
+        for _ in range(train_epoch_steps):
+            batch = next(train_iter)
+            images_batch = batch["image"]
+            if cfg.training.random_target_models > 0:
+                raise NotImplementedError("random_target_models > 0 is not supported (breaks data-parallel reduction in the reference too)")
+            target_features_batch = {t: batch[t]["embedding"].float() for t in target_model_names}
+            pred = rvfm(images_batch)
+            losses = rvfm.module.get_loss(pred, target_features_batch, as_float=False)
+            main_loss = select_main_loss(losses, cfg.training.main_loss)
+            optimizer.zero_grad()
+            main_loss.backward()
+            if cfg.training.grad_clip:
+                nn.utils.clip_grad_norm_(rvfm.parameters(), cfg.training.grad_clip_norm_warmup if steps < warmup_steps else cfg.training.grad_clip_norm)
+            optimizer.step()
+            if lr_scheduler is not None:
+                lr_scheduler.step()
+            steps += 1
+            if rank == 0 and steps % log_interval == 0:
+                ml = float(main_loss.detach())
+                history["train_main_loss"].append((steps, ml))
+                print(f"[train] ep {ep} step {steps}/{total_train_steps} main_loss {ml:.5f} "
+                      f"({(time.time() - t0) / max(1, steps % train_epoch_steps or train_epoch_steps) * 1e3:.1f} ms/step)", flush=True)
+            if cfg.training.freeze_translator and steps == int(cfg.training.freeze_translator_start_steps_ratio * total_train_steps):
+                rvfm.module.freeze_translator()
+            if steps % cfg.logging.save_ckpt_interval == 0 and rank == 0:
+                save_checkpoint(rvfm.module, cfg, steps)
+        if dist.is_initialized():
+            dist.barrier()
+        rvfm.eval()
+        with torch.no_grad():
+            acc, n = 0.0, 0
+            for _ in range(eval_epoch_steps):
+                batch = next(eval_iter)
+                target_features_batch = {t: batch[t]["embedding"].float() for t in target_model_names}
+                pred = rvfm(batch["image"])
+                losses = rvfm.module.get_loss(pred, target_features_batch, as_float=False)
+                acc += float(select_main_loss(losses, cfg.training.main_loss))
+                n += 1
+            if rank == 0 and n:
+                history["eval_main_loss"].append((steps, acc / n))
+                print(f"[eval] ep {ep} main_loss {acc / n:.5f}", flush=True)
+        if rank == 0:
+            save_checkpoint(rvfm.module, cfg, steps)
+        if dist.is_initialized():
+            dist.barrier()
+    return history
+
+
+def save_checkpoint(model: nn.Module, cfg, steps: int) -> str:
+    """Model-only state_dict, reference file naming (train_rvfm.py:153-156)."""
+    os.makedirs(cfg.logging.model_path, exist_ok=True)
+    path = osp.join(cfg.logging.model_path, f"{cfg.logging.run_identifier_prefix}_step{steps:08d}.pth")
+    torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, path)
+    return path
+
+
+def ddp_setup() -> None:
+    if "RANK" in os.environ and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")  # RCCL on ROCm
+
+
+def ddp_cleanup() -> None:
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def ddp_main(cfg) -> dict:
+    ddp_setup()
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world_size = dist.get_world_size() if dist.is_initialized() else 1
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    names = cfg.training.target_models.target_model_names
+    target_model_names = list(names) if len(names) > 0 else list(MODEL_FEATURE_SIZES.keys())
+    target_model_names = [t for t in target_model_names if "llava" not in t]
+    target_feature_sizes = {t: get_model_feature_size(t, keep_spatial=True) for t in target_model_names}
+    if cfg.training.get("distill_cls", False):
+        raise NotImplementedError("CLS-token distillation heads are outside the hot path (SURVEY.md sec. 8f-5)")
+
+    rvfm = RobotVisionFM(translator=cfg.model.translator.type, translator_kwargs=cfg.model.translator.kwargs,
+                         target_feature_sizes=target_feature_sizes,
+                         target_loss_weights=cfg.training.target_models.target_model_weights,
+                         precision=cfg.get("precision", None), **cfg.model.backbone)
+    rvfm.to(device)
+    rvfm_ddp = TheiaDataParallel(rvfm)
+
+    if "synthetic" not in cfg.dataset.dataset_mix:
+        raise NotImplementedError("the webdataset shard reader is outside the accelerated hot path; run with dataset=synthetic "
+                                  "or feed batches in the reference format to train()")
+    train_epoch_steps = int(cfg.dataset.get("train_steps_per_epoch", 20))
+    eval_epoch_steps = int(cfg.dataset.get("eval_steps_per_epoch", 2))
+    fixed = bool(cfg.dataset.get("fixed_batch", False))
+    train_iter = SyntheticFrames(cfg.training.batch_size, target_model_names, device, cfg.seed + rank * 100, fixed)
+    eval_iter = SyntheticFrames(cfg.training.batch_size, target_model_names, device, cfg.seed + (rank * 100 if fixed else 7777), fixed)
+    total_train_steps = train_epoch_steps * cfg.training.epochs
+
+    lr = cfg.training.base_lr * ((cfg.training.batch_size * world_size) / (cfg.training.base_batch_size * cfg.training.base_world_size))
+    if cfg.training.optimizer.get("_target_", "") in ("torch.optim.AdamW", "theia_amd.optimizers.FusedAdamW") and not cfg.training.grad_clip:
+        # same update rule as torch.optim.AdamW, fused over the engine's flat buckets (2 HIP launches per bucket)
+        optimizer = FusedAdamW(rvfm_ddp, lr=lr, betas=tuple(cfg.training.optimizer.get("betas", (0.9, 0.999))),
+                               weight_decay=cfg.training.weight_decay)
+        lr_scheduler = _HostLR(optimizer, int(cfg.training.warm_up_steps_ratio * total_train_steps),
+                               cfg.training.lr_scheduler.get("warm_up_lr_start_factor", 1e-2))
+    else:
+        groups = param_groups_weight_decay(rvfm_ddp, cfg.training.weight_decay)
+        optimizer = cfglib.instantiate(cfg.training.optimizer, groups, lr=lr)
+        lr_scheduler = cfglib.instantiate(cfg.training.lr_scheduler, optimizer=optimizer,
+                                          warm_up_steps=int(cfg.training.warm_up_steps_ratio * total_train_steps),
+                                          cos_lrs_T_0=int(total_train_steps * (1 - cfg.training.warm_up_steps_ratio)))
+    if rank == 0:
+        print(cfglib.to_yaml(cfg), flush=True)
+    history = train(rvfm_ddp, target_model_names, optimizer, lr_scheduler, train_iter, eval_iter, cfg=cfg, device=local_rank,
+                    train_epoch_steps=train_epoch_steps, eval_epoch_steps=eval_epoch_steps, total_train_steps=total_train_steps,
+                    warmup_steps=int(cfg.training.warm_up_steps_ratio * total_train_steps))
+    ddp_cleanup()
+    return history
+
+
+class _HostLR:
+    """Linear warm-up -> constant (reference default schedule, lr_schedulers.py:41-77) for FusedAdamW."""
+
+    def __init__(self, opt: FusedAdamW, warm_up_steps: int, start_factor: float):
+        self.opt, self.n, self.f0, self.base, self.k = opt, max(1, warm_up_steps), start_factor, opt.param_groups[0]["lr"], 0
+        self._apply()
+
+    def _apply(self) -> None:
+        f = self.f0 + (1.0 - self.f0) * min(1.0, self.k / self.n)
+        self.opt.param_groups[0]["lr"] = self.base * f
+
+    def step(self) -> None:
+        self.k += 1
+        self._apply()
+
+
+def main(argv=None) -> dict:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    config_path = None
+    if "--config-path" in argv:
+        i = argv.index("--config-path")
+        config_path = argv[i + 1]
+        del argv[i:i + 2]
+    cfg = cfglib.compose(argv, config_path=config_path)
+    backbone_fn = f"_{cfg.model.backbone.backbone.replace('/', '-')}"
+    notes_fn = f"_{cfg.logging.notes}" if cfg.logging.notes else ""
+    translator_fn = f"_{cfg.model.translator.type}"
+    pretrained_fn = "_pretrained" if cfg.model.backbone.pretrained else ""
+    dp_fn = f"_dp{cfg.dataset.dataset_ratio:.3f}"
+    cfg.logging.run_identifier_prefix = f"rvfm{dp_fn}{backbone_fn}{translator_fn}{pretrained_fn}{notes_fn}"
+    seed_everything(cfg.seed)
+    return ddp_main(cfg)
+
+
+if __name__ == "__main__":
+    main()
