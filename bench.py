@@ -160,11 +160,25 @@ def main():
             step()
         torch.cuda.synchronize()
         recs, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
-        dom = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, var, _s) in recs if var == "128x128"]
-        allg = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, var, _s) in recs]
+        allg = [(e0.elapsed_time(e1) * 1e-3, fl, var) for (e0, e1, fl, var, _s) in recs]
+        tot_by_var = {}
+        for t_, _f, v_ in allg:
+            tot_by_var[v_] = tot_by_var.get(v_, 0.0) + t_
+        dom_var = max(tot_by_var, key=tot_by_var.get)  # the tile variant with the largest share of the step
+        dom = [(t_, f_) for t_, f_, v_ in allg if v_ == dom_var]
+        allg = [(t_, f_) for t_, f_, _v in allg]
+        if os.environ.get("THEIA_BENCH_GEMM_TABLE") and rank == 0:  # per-shape table on stderr (tuning aid)
+            by = {}
+            for (e0, e1, fl, var, shp) in recs:
+                d = by.setdefault((var,) + shp, [0, 0.0, 0.0])
+                d[0] += 1
+                d[1] += e0.elapsed_time(e1) * 1e-3
+                d[2] += fl
+            for k, (cnt, tt, ff) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+                log(f"gemm_nt {k}: {cnt // 2:4d}/step  {tt / cnt * 1e6:8.1f} us  {ff / tt / 1e12:7.1f} TF  {tt / 2 * 1e3:7.2f} ms/step")
         tsum, fsum = sum(t for t, _ in dom), sum(f for _, f in dom)
         achieved = fsum / tsum / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel<bf16,128,128> (theia_gemm_nt)", "achieved": round(achieved, 1),
+        roofline = {"bound": "mfma", "kernel": f"gemm_nt_kernel<{'bf16' if args.precision == 'bf16' else 'f32'},{dom_var.replace('x', ',')}> (theia_gemm_nt)", "achieved": round(achieved, 1),
                     "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
                     "traffic": None, "launches_per_step": len(dom) // 2, "avg_launch_us": round(tsum / len(dom) * 1e6, 1),
                     "flops_per_launch": round(fsum / len(dom)), "gemm_nt_time_share_of_step": round(sum(t for t, _ in allg) / 2 / (dt / args.steps), 3)}

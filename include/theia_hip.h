@@ -102,6 +102,8 @@ typedef struct theia_gemm_args {
 } theia_gemm_args_t;
 
 int theia_gemm_nt(const theia_gemm_args_t* args, int dtype, void* stream);
+/* tile the launcher picks for an (M, N) problem: BM*1000 + BN (128128, 128064 or 256256) -- for profiling tools */
+int theia_gemm_nt_tile(int M, int N, int dtype);
 
 /*
  * Weight gradient:  slab[s][n][wslot[t]*in_c + ci] = sum_{m in split s} dY[m, n] * A[m, (t, ci)]

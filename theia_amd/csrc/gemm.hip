@@ -13,10 +13,10 @@
 // The MFMA is issued with the WEIGHT fragment as its A operand and the ACTIVATION fragment as its B operand, so a
 // lane ends up with 4 consecutive n for one m: the accumulator tile goes to LDS with ds_write_b128 and is re-read
 // row-contiguously, giving a fully vectorised epilogue (16-byte bias/residual/aux loads and output stores).
-#include "common.h"
+#include "gemm_tile.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
-typedef __attribute__((ext_vector_type(4))) float f32x4_v;
+typedef gt_f32x4 f32x4_v;
 typedef __attribute__((ext_vector_type(4))) short s16x4_v;
 
 template <typename T> struct Mma;
@@ -49,16 +49,22 @@ __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + 
 // ================================================================================================
 // NT implicit GEMM
 // ================================================================================================
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const theia_gemm_args_t p) {
+int theia_gemm_nt_ring_launch(const theia_gemm_args_t* a, int dtype, int tile, hipStream_t stream);  // gemm_ring.hip
+
+__device__ uint4 g_zero_page[16];  // 256 B of zeros: source of out-of-range operand chunks in the GLDS path
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GLDS>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const theia_gemm_args_t p) {
     constexpr int KT = 128 / (int)sizeof(T);   // k elements per LDS row
     constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int FM = WM / 16, FN = WN / 16;
-    constexpr int NPA = BM / 32, NPB = BN / 32;
+    constexpr int NTHR = 64 * WAVES_M * WAVES_N;  // 256 (128x128 / 128x64 tiles) or 512 (256x256 tile)
+    constexpr int SRP = NTHR / 8;                  // rows staged per pass (8 x 16-byte chunks per row)
+    constexpr int NPA = BM / SRP, NPB = BN / SRP;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int EP_PITCH = WN + 4;  // floats
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    static_assert(BM % SRP == 0 && BN % SRP == 0 && (SRP % 16) == 0, "staging geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const theia_gemm_args_t p)
     int a_iy0[NPA], a_ix0[NPA];
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
-        const int m = m0 + st_row + 32 * i;
+        const int m = m0 + st_row + SRP * i;
         if (m < p.M) {
             const int img = m / R, rem = m - img * R;
             const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const theia_gemm_args_t p)
     bool w_ok[NPB];
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
-        const int n = n0 + st_row + 32 * i;
+        const int n = n0 + st_row + SRP * i;
         w_ok[i] = n < p.N;
         w_base[i] = (int64_t)n * p.ldw;
     }
@@ -126,9 +132,39 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const theia_gemm_args_t p)
         char* sa = smem + stage * STAGE;
         char* sb = sa + BM * 128;
 #pragma unroll
-        for (int i = 0; i < NPA; ++i) *reinterpret_cast<uint4*>(sa + swz_off(st_row + 32 * i, st_chunk)) = ra[i];
+        for (int i = 0; i < NPA; ++i) *reinterpret_cast<uint4*>(sa + swz_off(st_row + SRP * i, st_chunk)) = ra[i];
 #pragma unroll
-        for (int i = 0; i < NPB; ++i) *reinterpret_cast<uint4*>(sb + swz_off(st_row + 32 * i, st_chunk)) = rb[i];
+        for (int i = 0; i < NPB; ++i) *reinterpret_cast<uint4*>(sb + swz_off(st_row + SRP * i, st_chunk)) = rb[i];
+    };
+
+    // GLDS staging: global_load_lds_dwordx4 writes LDS lane-linearly (wave-uniform base + lane*16), so the XOR swizzle is
+    // applied on the SOURCE side: the lane that fills slot s of row r fetches logical chunk s ^ ((r>>1)&7).  Rows that are
+    // out of range / taps that fall outside the image read a 256-byte page of zeros instead (no predication).
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int lchunk = st_chunk ^ ((st_row >> 1) & 7);
+    auto issue_tile = [&](int kt, int stage) {
+        const int k0 = kt * KT;
+        const int tap = k0 / mp.in_c;
+        const int c = k0 - tap * mp.in_c + lchunk * EPC;
+        const bool cok = c < mp.in_c;
+        const int dy = mp.dy[tap], dx = mp.dx[tap];
+        const int64_t wcol = (int64_t)mp.wslot[tap] * mp.in_c + c;
+        char* sa = smem + stage * STAGE + uwave * (8 * 128);
+        char* sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+            const bool ok = cok && iy >= 0 && iy < mp.in_h && ix >= 0 && ix < mp.in_w;
+            const T* src = ok ? A + a_base[i] + (int64_t)(iy * mp.in_w + ix) * mp.in_c + c : reinterpret_cast<const T*>(g_zero_page);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sa + i * (SRP * 128)), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const T* src = (cok && w_ok[i]) ? W + w_base[i] + wcol : reinterpret_cast<const T*>(g_zero_page);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sb + i * (SRP * 128)), 16, 0, 0);
+        }
     };
 
     f32x4_v acc[FN][FM];
@@ -138,14 +174,81 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const theia_gemm_args_t p)
         for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_v){0.f, 0.f, 0.f, 0.f};
 
     const int nkt = (p.K + KT - 1) / KT;
-    load_tile(0);
-    store_tile(0);
+    if constexpr (GLDS) {
+        issue_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        load_tile(0);
+        store_tile(0);
+    }
     __syncthreads();
 
     const int frow = lane & 15, fg = lane >> 4;
-    for (int kt = 0; kt < nkt; ++kt) {
+    if constexpr (GLDS) {
+        // Branch-free single-block main loop: the source address of every LDS-DMA piece is selected with bit masks (no
+        // divergent branches around the loads) and the last iteration simply re-fetches the last tile into the idle slot
+        // instead of branching, so the compiler keeps the accumulators in place across iterations.
+        const uint64_t zp = reinterpret_cast<uint64_t>(g_zero_page);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            const int ktn = min(kt + 1, nkt - 1);
+            const int k0 = ktn * KT;
+            const int tap = k0 / mp.in_c;
+            const int c = k0 - tap * mp.in_c + lchunk * EPC;
+            const bool cok = c < mp.in_c;
+            const int dy = mp.dy[tap], dx = mp.dx[tap];
+            const int64_t wcol = (int64_t)mp.wslot[tap] * mp.in_c + c;
+            char* na = smem + (cur ^ 1) * STAGE + uwave * (8 * 128);
+            char* nb = na + BM * 128;
+            const char* sa = smem + cur * STAGE;
+            const char* sb = sa + BM * 128;
+            auto issue_piece = [&](int q) {
+                uint64_t src;
+                char* dst;
+                if (q < NPA) {
+                    const int iy = a_iy0[q] + dy, ix = a_ix0[q] + dx;
+                    const bool ok = cok & (iy >= 0) & (iy < mp.in_h) & (ix >= 0) & (ix < mp.in_w);
+                    const uint64_t pa = reinterpret_cast<uint64_t>(A + a_base[q] + (int64_t)(iy * mp.in_w + ix) * mp.in_c + c);
+                    const uint64_t msk = 0ull - (uint64_t)ok;
+                    src = (pa & msk) | (zp & ~msk);
+                    dst = na + q * (SRP * 128);
+                } else {
+                    const int i = q - NPA;
+                    const bool ok = cok & w_ok[i];
+                    const uint64_t pw = reinterpret_cast<uint64_t>(W + w_base[i] + wcol);
+                    const uint64_t msk = 0ull - (uint64_t)ok;
+                    src = (pw & msk) | (zp & ~msk);
+                    dst = nb + i * (SRP * 128);
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            };
+            // all pieces first: with two LDS stages the prefetch must land within this iteration, so it is issued as early
+            // as possible (spreading it between the MFMA groups measured 30 % slower: the last piece's latency is exposed)
+#pragma unroll
+            for (int q = 0; q < NPA + NPB; ++q) issue_piece(q);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                uint4 fb[FN];
+#pragma unroll
+                for (int i = 0; i < FN; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz_off(wn * WN + i * 16 + frow, kk * 4 + fg));
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    const uint4 fa = *reinterpret_cast<const uint4*>(sa + swz_off(wm * WM + j * 16 + frow, kk * 4 + fg));
+#pragma unroll
+                    for (int i = 0; i < FN; ++i) Mma<T>::run(acc[i][j], fb[i], fa);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 has landed
+            __syncthreads();
+        }
+    }
+    for (int kt = 0; !GLDS && kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
+        if (kt + 1 < nkt) {
+            if constexpr (GLDS) issue_tile(kt + 1, cur ^ 1);
+            else load_tile(kt + 1);
+        }
         const char* sa = smem + cur * STAGE;
         const char* sb = sa + BM * 128;
 #pragma unroll
@@ -160,97 +263,52 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const theia_gemm_args_t p)
 #pragma unroll
                 for (int j = 0; j < FM; ++j) Mma<T>::run(acc[i][j], fb[i], fa[j]);
         }
-        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        if constexpr (GLDS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile has landed in LDS
+        } else {
+            if (kt + 1 < nkt) store_tile(cur ^ 1);
+        }
         __syncthreads();
     }
 
-    // ---- epilogue: accumulators -> per-wave LDS tile [WM][WN+4] f32 -> row-contiguous vector epilogue ----
-    float* ep = reinterpret_cast<float*>(smem) + wave * (WM * EP_PITCH);
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-            float* q = ep + (j * 16 + frow) * EP_PITCH + i * 16 + fg * 4;
-            *reinterpret_cast<float4*>(q) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        }
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own-wave LDS writes done (wave-private region)
-    __builtin_amdgcn_wave_barrier();
-
-    constexpr int LPR = WN / 8;        // lanes per row
-    constexpr int RPP = 64 / LPR;      // rows per pass
-    T* __restrict__ O = reinterpret_cast<T*>(p.out);
-    const T* __restrict__ RES = reinterpret_cast<const T*>(p.resid);
-    const T* __restrict__ AUXI = reinterpret_cast<const T*>(p.aux_in);
-    T* __restrict__ AUXO = reinterpret_cast<T*>(p.aux_out);
-    const int col = (lane % LPR) * 8;
-    const int n = n0 + wn * WN + col;
-    float bias8[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bias8[j] = 0.f;
-    if (p.bias != nullptr && n < p.N) load8(p.bias + n, bias8);
-#pragma unroll
-    for (int ps = 0; ps < WM / RPP; ++ps) {
-        const int row = ps * RPP + lane / LPR;
-        const int m = m0 + wm * WM + row;
-        if (m >= p.M || n >= p.N) continue;
-        float v[8];
-        load8(ep + row * EP_PITCH + col, v);
-        const int img = m / R, rem = m - img * R;
-        const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
-        const int64_t o = (int64_t)img * mp.out_batch_stride + mp.out_offset +
-                          (int64_t)((ry * mp.out_sy + mp.out_y0) * mp.out_w + rx * mp.out_sx + mp.out_x0) * p.ldo + n;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += bias8[j];
-        if (p.rowtab != nullptr) {
-            float t8[8];
-            load8(p.rowtab + (int64_t)(m % p.rowtab_period) * p.N + n, t8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += t8[j];
-        }
-        if (p.act == THEIA_ACT_GELU) {
-            if (AUXO != nullptr) store8(AUXO + o, v);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
-        } else if (p.act == THEIA_ACT_RELU) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-        } else if (p.act == THEIA_ACT_MUL_DGELU) {
-            float a8[8];
-            load8(AUXI + o, a8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] *= gelu_erf_grad(a8[j]);
-        } else if (p.act == THEIA_ACT_MUL_DRELU) {
-            float a8[8];
-            load8(AUXI + o, a8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = a8[j] > 0.f ? v[j] : 0.f;
-        }
-        if (RES != nullptr) {
-            float r8[8];
-            load8(RES + o, r8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += r8[j];
-        }
-        store8(O + o, v);
-    }
+    // ---- epilogue (shared with the ring kernel): wave-private LDS round trip, 16-byte vector global accesses ----
+    float* ep = reinterpret_cast<float*>(smem) + wave * ((WM > 64 ? 64 : WM) * EP_PITCH);
+    gt_epilogue<T, WM, WN>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-static int launch_gemm_nt(const theia_gemm_args_t* a, hipStream_t stream) {
+// THEIA_GEMM_STAGING=regs selects the register-staged variant (global -> VGPR -> ds_write); default is the LDS-DMA one
+static bool use_glds() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("THEIA_GEMM_STAGING");
+        v = (e != nullptr && strcmp(e, "regs") == 0) ? 0 : 1;
+    }
+    return v == 1;
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GLDS>
+static int launch_gemm_nt_v(const theia_gemm_args_t* a, hipStream_t stream) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int NTHR = 64 * WAVES_M * WAVES_N;
     constexpr int stage_bytes = 2 * (BM + BN) * 128;
-    constexpr int ep_bytes = 4 * WM * (WN + 4) * 4;
+    constexpr int ep_bytes = WAVES_M * WAVES_N * (WM > 64 ? 64 : WM) * (WN + 4) * 4;
     constexpr int lds = stage_bytes > ep_bytes ? stage_bytes : ep_bytes;
-    auto kern = gemm_nt_kernel<T, BM, BN, WAVES_M, WAVES_N>;
+    auto kern = gemm_nt_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int tiles = cdiv_i(a->M, BM) * cdiv_i(a->N, BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, stream, *a);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHR), lds, stream, *a);
     THEIA_CHECK_LAUNCH("theia_gemm_nt");
     return THEIA_OK;
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_gemm_nt(const theia_gemm_args_t* a, hipStream_t stream) {
+    return use_glds() ? launch_gemm_nt_v<T, BM, BN, WAVES_M, WAVES_N, true>(a, stream)
+                      : launch_gemm_nt_v<T, BM, BN, WAVES_M, WAVES_N, false>(a, stream);
 }
 
 static int check_rowmap(const theia_rowmap_t& m, int kt, const char* who) {
@@ -259,6 +317,30 @@ static int check_rowmap(const theia_rowmap_t& m, int kt, const char* who) {
     THEIA_CHECK_ARG(m.in_c >= 1, "%s: in_c=%d", who, m.in_c);
     THEIA_CHECK_ARG(m.ntaps == 1 || m.in_c % kt == 0, "%s: in_c=%d must be a multiple of %d for a multi-tap gather", who, m.in_c, kt);
     return THEIA_OK;
+}
+
+// Tile chooser (BM*1000 + BN).  128x64 when a 128-wide N tile would waste > 12 % of the MFMA work.  For bf16 the 256x256
+// tile (8 waves, 1 block/CU) halves the L2->LDS bytes per flop of the 128x128 tile (2 blocks/CU); the kernel is bound by
+// operand-fetch latency x bytes in flight, so the big tile wins whenever it does not waste the grid:
+// score = useful fraction of the padded tile grid x fill of the last block wave x relative per-CU rate.
+extern "C" int theia_gemm_nt_tile(int M, int N, int dtype) {
+    const int t128 = cdiv_i(N, 128) * 128;
+    if ((t128 - N) * 8 > t128) return 128064;
+    if (dtype != THEIA_BF16) return 128128;
+    static int force = -1;
+    if (force < 0) {
+        const char* e = getenv("THEIA_GEMM_TILE");
+        force = e == nullptr ? 0 : atoi(e);
+    }
+    auto score = [&](int bm, int bn, int slots, double rate) {
+        const double tm = cdiv_i(M, bm), tn = cdiv_i(N, bn);
+        const double useful = ((double)M * N) / (tm * bm * tn * bn);
+        const double blocks = tm * tn;
+        const double fill = blocks / (cdiv_i((long)blocks, slots) * (double)slots);
+        return useful * fill * rate;
+    };
+    const bool big = force == 256 || (force == 0 && score(256, 256, 256, 1.0) > score(128, 128, 512, 0.6));
+    return big ? 256256 : 128128;
 }
 
 extern "C" int theia_gemm_nt(const theia_gemm_args_t* a, int dtype, void* stream) {
@@ -280,13 +362,20 @@ extern "C" int theia_gemm_nt(const theia_gemm_args_t* a, int dtype, void* stream
     int rc = check_rowmap(a->map, dtype == THEIA_BF16 ? 64 : 32, "theia_gemm_nt");
     if (rc) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    // narrow tile when a 128-wide N tile would waste > 12 % of the MFMA work
-    const int t128 = cdiv_i(a->N, 128) * 128;
-    const bool narrow = (t128 - a->N) * 8 > t128;
-    if (dtype == THEIA_BF16) {
-        return narrow ? launch_gemm_nt<bf16_t, 128, 64, 2, 2>(a, s) : launch_gemm_nt<bf16_t, 128, 128, 2, 2>(a, s);
+    const int tile = theia_gemm_nt_tile(a->M, a->N, dtype);
+    // default: the 2-stage LDS-DMA kernel below; THEIA_GEMM_KERNEL=ring selects the 4-deep half-tile ring of gemm_ring.hip
+    // (measured 15 % slower on MI355X: twice the barriers per k-tile outweigh the longer prefetch distance)
+    static int use_ring = -1;
+    if (use_ring < 0) {
+        const char* e = getenv("THEIA_GEMM_KERNEL");
+        use_ring = (e != nullptr && strcmp(e, "ring") == 0) ? 1 : 0;
     }
-    return narrow ? launch_gemm_nt<float, 128, 64, 2, 2>(a, s) : launch_gemm_nt<float, 128, 128, 2, 2>(a, s);
+    if (use_ring) return theia_gemm_nt_ring_launch(a, dtype, tile, s);
+    if (dtype == THEIA_BF16) {
+        if (tile == 256256) return launch_gemm_nt<bf16_t, 256, 256, 2, 4>(a, s);
+        return tile == 128064 ? launch_gemm_nt<bf16_t, 128, 64, 2, 2>(a, s) : launch_gemm_nt<bf16_t, 128, 128, 2, 2>(a, s);
+    }
+    return tile == 128064 ? launch_gemm_nt<float, 128, 64, 2, 2>(a, s) : launch_gemm_nt<float, 128, 128, 2, 2>(a, s);
 }
 
 // ================================================================================================
@@ -301,6 +390,15 @@ template <> struct WgTile<float> {
     static constexpr int MS = 32;
     static constexpr int PAD = 64;
 };
+
+// q = m / d, r = m % d for 0 <= m < 2^24 via a float reciprocal and one correction step (the row decode runs for every
+// staged row of every step: integer division made the kernel VALU-bound, 17 VALU instructions per MFMA)
+__device__ __forceinline__ void fast_divmod(int m, int d, float rcp, int& q, int& r) {
+    q = (int)((float)m * rcp);
+    r = m - q * d;
+    if (r >= d) { ++q; r -= d; }
+    if (r < 0) { --q; r += d; }
+}
 
 // BNN: n tile (dY columns), BC: c tile (A columns inside one tap)
 template <typename T, int BNN, int BC>
@@ -337,6 +435,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const theia_wgrad_args_
     const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
     const T* __restrict__ A = reinterpret_cast<const T*>(p.a);
     const int R = mp.rows_h * mp.rows_w;
+    const float rcpR = 1.0f / (float)R, rcpW = 1.0f / (float)mp.rows_w;  // row decode without integer division (M < 2^24)
 
     uint4 ry_[NCY], rx_[NCX];
     auto load_step = [&](int s) {
@@ -349,8 +448,9 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const theia_wgrad_args_
             const int n = n0 + ch * EPC;
             ry_[i] = make_uint4(0, 0, 0, 0);
             if (m < p.M && n < p.N) {
-                const int img = m / R, rem = m - img * R;
-                const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
+                int img, rem, ry, rx;
+                fast_divmod(m, R, rcpR, img, rem);
+                fast_divmod(rem, mp.rows_w, rcpW, ry, rx);
                 const int64_t o = (int64_t)img * mp.out_batch_stride + mp.out_offset +
                                   (int64_t)((ry * mp.out_sy + mp.out_y0) * mp.out_w + rx * mp.out_sx + mp.out_x0) * p.ldo + n;
                 ry_[i] = *reinterpret_cast<const uint4*>(DY + o);
@@ -363,8 +463,9 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const theia_wgrad_args_
             const int m = mbase + row;
             rx_[i] = make_uint4(0, 0, 0, 0);
             if (m < p.M) {
-                const int img = m / R, rem = m - img * R;
-                const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
+                int img, rem, ry, rx;
+                fast_divmod(m, R, rcpR, img, rem);
+                fast_divmod(rem, mp.rows_w, rcpW, ry, rx);
                 const int iy = ry * mp.in_sy + dy, ix = rx * mp.in_sx + dx;
                 if (iy >= 0 && iy < mp.in_h && ix >= 0 && ix < mp.in_w) {
                     const int64_t o = (int64_t)img * mp.in_batch_stride + mp.in_offset + (int64_t)(iy * mp.in_w + ix) * mp.in_c + c0 + ch * EPC;
@@ -504,7 +605,7 @@ extern "C" int theia_gemm_wgrad(const theia_wgrad_args_t* a, int dtype, void* st
     THEIA_CHECK_ARG(a != nullptr, "theia_gemm_wgrad: null args");
     THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16, "theia_gemm_wgrad: bad dtype %d", dtype);
     THEIA_CHECK_ARG(a->dy && a->a && a->slabs, "theia_gemm_wgrad: null pointer");
-    THEIA_CHECK_ARG(a->M > 0 && a->N > 0 && a->splits >= 1, "theia_gemm_wgrad: bad shape");
+    THEIA_CHECK_ARG(a->M > 0 && a->M < (1 << 24) && a->N > 0 && a->splits >= 1, "theia_gemm_wgrad: bad shape (M must be < 2^24)");
     THEIA_CHECK_ARG(a->N % 8 == 0, "theia_gemm_wgrad: N=%d must be a multiple of 8", a->N);
     THEIA_CHECK_ARG(a->map.in_c % 64 == 0, "theia_gemm_wgrad: in_c=%d must be a multiple of 64", a->map.in_c);
     THEIA_CHECK_ARG(a->ldo % 8 == 0 && a->map.out_offset % 8 == 0 && a->map.out_batch_stride % 8 == 0 &&

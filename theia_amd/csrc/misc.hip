@@ -190,23 +190,33 @@ extern "C" int theia_write_cls(const float* cls, const float* pos, void* h, int 
 // ------------------------------------------------------------------------------------------------
 // bias gradient: column sums of a [M, N] matrix.  Block = 64 column-vectors(8) x 4 row lanes; two stages.
 // ------------------------------------------------------------------------------------------------
-constexpr int CS_ROWS = 512;  // rows per block in stage 1
-static int colsum_rowblocks(int64_t M) { return (int)((M + CS_ROWS - 1) / CS_ROWS); }
+// Stage 1: block = 32 column-vectors (256 columns) x 8 row lanes over a row chunk sized so that there are at most 256
+// partial rows (grid = N/256 x <=256 blocks: fills the chip for every hot-path shape).  Stage 2: 64 columns x 4 part lanes.
+constexpr int CS_MAXPARTS = 256;
+static int colsum_rows_per_block(int64_t M) {
+    int64_t r = (M + CS_MAXPARTS - 1) / CS_MAXPARTS;
+    r = (r + 7) / 8 * 8;
+    return (int)(r < 8 ? 8 : r);
+}
+static int colsum_rowblocks(int64_t M) {
+    const int rpb = colsum_rows_per_block(M);
+    return (int)((M + rpb - 1) / rpb);
+}
 extern "C" size_t theia_colsum_workspace_bytes(int64_t M, int N) { return (size_t)colsum_rowblocks(M) * N * sizeof(float); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t M, int N, int64_t ld,
-                                                     float* __restrict__ part) {
-    __shared__ float red[4][64][8];
-    const int cv = blockIdx.x * 64 + (threadIdx.x & 63);  // column vector index
-    const int rl = threadIdx.x >> 6;
-    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+                                                     float* __restrict__ part, int rows_per_block) {
+    __shared__ float red[8][32][9];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int cv = blockIdx.x * 32 + cl;  // column vector index
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     float a[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = 0.f;
     if (cv * 8 < N) {
-        const int64_t r1 = min(M, r0 + CS_ROWS);
-        for (int64_t r = r0 + rl; r < r1; r += 4) {
+        const int64_t r1 = min(M, r0 + rows_per_block);
+        for (int64_t r = r0 + rl; r < r1; r += 8) {
             float v[8];
             load8(x + r * ld + cv * 8, v);
 #pragma unroll
@@ -214,32 +224,46 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[rl][threadIdx.x & 63][j] = a[j];
+    for (int j = 0; j < 8; ++j) red[rl][cl][j] = a[j];
     __syncthreads();
     if (rl == 0 && cv * 8 < N) {
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = red[0][threadIdx.x][j] + red[1][threadIdx.x][j] + red[2][threadIdx.x][j] + red[3][threadIdx.x][j];
+        for (int j = 0; j < 8; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += red[k][cl][j];
+            o[j] = s;
+        }
         store8(part + (int64_t)blockIdx.y * N + cv * 8, o);
     }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+// out[c] (+)= sum_p part[p*N + c]: 64 columns x 4 part lanes per block, fixed summation order
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out,
+                                                           int accumulate) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * N + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < N)
+        for (int p = pl; p < nparts; p += 4) s += part[(int64_t)p * N + c];
+    red[pl][cl] = s;
+    __syncthreads();
+    if (pl == 0 && c < N) {
+        s = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 extern "C" int theia_colsum(const void* x, int64_t M, int N, int64_t ld, float* out, float* workspace, int accumulate,
                             int dtype, void* stream) {
     THEIA_CHECK_ARG(x && out && workspace && M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0, "theia_colsum: bad args (N, ld multiples of 8)");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int rb = colsum_rowblocks(M);
-    const dim3 grid((N / 8 + 63) / 64, rb);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, M, N, ld, workspace),
-               hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, M, N, ld, workspace), "theia_colsum");
+    const int rb = colsum_rowblocks(M), rpb = colsum_rows_per_block(M);
+    const dim3 grid((N / 8 + 31) / 32, rb);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, M, N, ld, workspace, rpb),
+               hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, M, N, ld, workspace, rpb), "theia_colsum");
     THEIA_CHECK_LAUNCH("theia_colsum");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, workspace, rb, N, out, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, s, workspace, rb, N, out, accumulate);
     THEIA_CHECK_LAUNCH("theia_colsum(final)");
     return THEIA_OK;
 }

@@ -157,19 +157,28 @@ __global__ __launch_bounds__(256) void ln_row_bwd_kernel(const T* __restrict__ d
 }
 
 // out[c] (+)= sum_p part[p][c]  for c in [0, ncol); deterministic order
-__global__ void partial_reduce_kernel(const float* __restrict__ part, int nparts, int ncol, int64_t pitch,
-                                      float* __restrict__ out0, float* __restrict__ out1, int split, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncol) return;
+// 64 columns x 4 part lanes per block (a thread-per-column loop over hundreds of partial rows is latency-bound)
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ part, int nparts, int ncol, int64_t pitch,
+                                                             float* __restrict__ out0, float* __restrict__ out1, int split,
+                                                             int accumulate) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * pitch + c];
-    float* dst = c < split ? out0 + c : out1 + (c - split);
-    *dst = accumulate ? *dst + s : s;
+    if (c < ncol)
+        for (int p = pl; p < nparts; p += 4) s += part[(int64_t)p * pitch + c];
+    red[pl][cl] = s;
+    __syncthreads();
+    if (pl == 0 && c < ncol) {
+        s = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        float* dst = c < split ? out0 + c : out1 + (c - split);
+        *dst = accumulate ? *dst + s : s;
+    }
 }
 
 static int ln_bwd_blocks(int64_t M) {
     int64_t b = (M + 3) / 4;
-    if (b > 1024) b = 1024;
+    if (b > 512) b = 512;
     return (int)b;
 }
 
@@ -192,7 +201,7 @@ extern "C" int theia_layernorm_bwd(const void* dy, const void* x, const float* g
     else
         THEIA_CHECK_ARG(false, "theia_layernorm_bwd: bad dtype %d", dtype);
     THEIA_CHECK_LAUNCH("theia_layernorm_bwd");
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, s, workspace, blocks, 2 * D,
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, workspace, blocks, 2 * D,
                        (int64_t)2 * D, dgamma, dbeta, D, accumulate);
     THEIA_CHECK_LAUNCH("theia_layernorm_bwd(reduce)");
     return THEIA_OK;
@@ -395,7 +404,7 @@ extern "C" int theia_layernorm_chw_bwd(const void* dy, const void* x, const floa
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_bwd(dx)");
     // reduce partials: columns [0,E) -> dgamma, [E,2E) -> dbeta
     const int64_t ncol = 2 * E;
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, s, parts, ng, (int)ncol,
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((ncol + 63) / 64)), dim3(256), 0, s, parts, ng, (int)ncol,
                        (int64_t)2 * E, dgamma, dbeta, (int)E, accumulate);
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_bwd(reduce)");
     return THEIA_OK;

@@ -125,8 +125,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int
         e0.record()
         N.check(N.lib().theia_gemm_nt(g, _dt(a), N.stream_ptr()), "theia_gemm_nt")
         e1.record()
-        t128 = (Nn + 127) // 128 * 128
-        GEMM_PROFILE.append((e0, e1, 2.0 * M * Nn * K, "128x64" if (t128 - Nn) * 8 > t128 else "128x128", (M, Nn, K)))
+        tile = N.lib().theia_gemm_nt_tile(M, Nn, _dt(a))
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * Nn * K, f"{tile // 1000}x{tile % 1000}", (M, Nn, K)))
         return out
     N.check(N.lib().theia_gemm_nt(g, _dt(a), N.stream_ptr()), "theia_gemm_nt")
     return out

@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Micro-benchmark of theia_gemm_nt / theia_gemm_wgrad on the hot-path shapes (tuning + rocprofv3 --pmc target).
+
+    python tools/gemm_bench.py [--what nt|wgrad|both] [--iters 20] [--shapes conv,fc1,...]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from theia_amd import ops  # noqa: E402
+
+SHAPES = {  # name: (M, N, K, kind)
+    "conv16": (32768, 768, 6912, "conv"),
+    "fc1": (25216, 3072, 768, "plain"),
+    "fc2": (25216, 768, 3072, "plain"),
+    "proj": (25216, 768, 768, "plain"),
+    "qkv": (25216, 2304, 768, "plain"),
+    "up64c": (131072, 768, 3072, "plain"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="both")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--shapes", default=",".join(SHAPES))
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    T = torch.bfloat16
+    for name in a.shapes.split(","):
+        M, N, K, kind = SHAPES[name]
+        C = 768
+        if kind == "conv":
+            b = M // 256
+            plan = ops.plan_conv3x3(C, 16)
+            rmap, mpi = plan.fwd[0]
+            x = torch.randn(b, 256 * C, device=dev).to(T)
+            w = (torch.randn(N, K, device=dev) * 0.02).to(T)
+            out = torch.empty(M, N, dtype=T, device=dev)
+
+            def run_nt():
+                ops.gemm_nt(x, w, out, M, N, K, rmap, K, N)
+            dy = torch.randn(M, N, device=dev).to(T)
+            splits = ops.wgrad_splits(M, N, K)
+            slabs = torch.empty(splits * N * K, dtype=torch.float32, device=dev)
+
+            def run_wg():
+                ops.gemm_wgrad(dy, x, slabs, M, N, N, 9, splits, rmap)
+        else:
+            x = torch.randn(M, K, device=dev).to(T)
+            w = (torch.randn(N, K, device=dev) * 0.02).to(T)
+            out = torch.empty(M, N, dtype=T, device=dev)
+
+            def run_nt():
+                ops.linear(x, w, out=out)
+            dy = torch.randn(M, N, device=dev).to(T)
+            g = torch.empty(N, K, dtype=torch.float32, device=dev)
+            ws = torch.empty(ops.wgrad_splits(M, N, K) * N * K, dtype=torch.float32, device=dev)
+
+            def run_wg():
+                ops.linear_wgrad(dy, x, g, False, ws)
+        for label, fn in (("nt", run_nt), ("wgrad", run_wg)):
+            if a.what not in (label, "both"):
+                continue
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / a.iters * 1e3
+            print(f"{label:5s} {name:7s} M={M} N={N} K={K}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF", flush=True)
+
+
+if __name__ == "__main__":
+    main()
