@@ -96,7 +96,8 @@ def test_linear_bias_epilogues(dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(197 * 4, 192, 192), (1000, 128, 256), (4096 + 37, 64, 64), (513, 1280, 192), (300, 32, 384)])
+@pytest.mark.parametrize("M,N,K", [(197 * 4, 192, 192), (1000, 128, 256), (4096 + 37, 64, 64), (513, 1280, 192), (300, 32, 384),
+                                   (197 * 9, 768, 768), (2000, 3072, 768), (5000, 256, 768), (96, 1280, 768)])
 def test_linear_wgrad_and_colsum(dt, M, N, K):
     from theia_amd import ops
     dev = _dev()
@@ -128,11 +129,12 @@ def _pack(plan_pack, w, dt, dev):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("kind", ["conv_p1", "convT_s1", "convT_s2_p1", "convT_s2_op1"])
-def test_conv_family_fwd_dgrad_wgrad(dt, kind):
+@pytest.mark.parametrize("C", [64, 256])  # 256 channels exercises the 256x256 ping-pong tiles (in_c % 256 == 0)
+def test_conv_family_fwd_dgrad_wgrad(dt, kind, C):
     """Implicit-GEMM convolutions vs the oracle's shifted-matmul restatement (itself pinned to torch by G10)."""
     from theia_amd import ops, _native as Nn
     dev = _dev()
-    C, b = 64, 3
+    b = 3
     IH = {"conv_p1": 16, "convT_s1": 14, "convT_s2_p1": 16, "convT_s2_op1": 31}[kind]
     x = h((b, IH, IH, C), 21, 1.0)
     W = h((C, C, 3, 3), 22, 1.0 / math.sqrt(9 * C))

@@ -50,6 +50,7 @@ __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + 
 // NT implicit GEMM
 // ================================================================================================
 int theia_gemm_nt_ring_launch(const theia_gemm_args_t* a, int dtype, int tile, hipStream_t stream);  // gemm_ring.hip
+int theia_gemm_nt_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t stream);               // gemm_pp.hip
 
 __device__ uint4 g_zero_page[16];  // 256 B of zeros: source of out-of-range operand chunks in the GLDS path
 
@@ -363,14 +364,15 @@ extern "C" int theia_gemm_nt(const theia_gemm_args_t* a, int dtype, void* stream
     if (rc) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int tile = theia_gemm_nt_tile(a->M, a->N, dtype);
-    // default: the 2-stage LDS-DMA kernel below; THEIA_GEMM_KERNEL=ring selects the 4-deep half-tile ring of gemm_ring.hip
-    // (measured 15 % slower on MI355X: twice the barriers per k-tile outweigh the longer prefetch distance)
+    // 256x256 tiles default to the ping-pong kernel (gemm_pp.hip: two wave groups one barrier apart, 4-deep LDS-DMA ring);
+    // smaller tiles use the 2-stage kernel below.  THEIA_GEMM_KERNEL=std|ring|pp overrides (A/B measurements).
     static int use_ring = -1;
     if (use_ring < 0) {
         const char* e = getenv("THEIA_GEMM_KERNEL");
-        use_ring = (e != nullptr && strcmp(e, "ring") == 0) ? 1 : 0;
+        use_ring = (e != nullptr && strcmp(e, "ring") == 0) ? 1 : (e != nullptr && strcmp(e, "std") == 0) ? 0 : 2;
     }
-    if (use_ring) return theia_gemm_nt_ring_launch(a, dtype, tile, s);
+    if (use_ring == 1) return theia_gemm_nt_ring_launch(a, dtype, tile, s);
+    if (use_ring == 2 && tile == 256256 && a->K % (dtype == THEIA_BF16 ? 32 : 16) == 0) return theia_gemm_nt_pp_launch(a, dtype, s);  // ping-pong wave groups (gemm_pp.hip)
     if (dtype == THEIA_BF16) {
         if (tile == 256256) return launch_gemm_nt<bf16_t, 256, 256, 2, 4>(a, s);
         return tile == 128064 ? launch_gemm_nt<bf16_t, 128, 64, 2, 2>(a, s) : launch_gemm_nt<bf16_t, 128, 128, 2, 2>(a, s);
@@ -590,7 +592,27 @@ static int launch_wgrad(const theia_wgrad_args_t* a, hipStream_t stream) {
     return THEIA_OK;
 }
 
+int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream);  // gemm_wgrad_pp.hip
+
+static bool wgrad_use_pp() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("THEIA_WGRAD_KERNEL");
+        v = (e != nullptr && strcmp(e, "std") == 0) ? 0 : 1;
+    }
+    return v == 1;
+}
+
 extern "C" int theia_wgrad_splits(int M, int N, int Ktot) {
+    if (wgrad_use_pp() && Ktot % 256 == 0 && N >= 128) {
+        // ping-pong kernel: 256x256 output tiles, one workgroup per CU -> fill one round of 256 CUs as exactly as possible
+        const int tiles = cdiv_i(N, 256) * (Ktot / 256);
+        int s = 256 / (tiles > 0 ? tiles : 1);
+        const int smax = cdiv_i(M, 32) / 8;
+        if (s > smax) s = smax;
+        if (s > 64) s = 64;
+        return s < 1 ? 1 : s;
+    }
     const int tiles = cdiv_i(N, 128) * cdiv_i(Ktot, 128);
     const int nsteps = cdiv_i(M, 64);
     int s = cdiv_i(768, tiles > 0 ? tiles : 1);
@@ -616,6 +638,10 @@ extern "C" int theia_gemm_wgrad(const theia_wgrad_args_t* a, int dtype, void* st
     int rc = check_rowmap(a->map, 64, "theia_gemm_wgrad");
     if (rc) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == THEIA_BF16 && wgrad_use_pp()) {
+        rc = theia_gemm_wgrad_pp_launch(a, s);
+        if (rc != THEIA_ERR_UNSUPPORTED) return rc;
+    }
     const bool n128 = a->N % 128 == 0, c128 = a->map.in_c % 128 == 0;
     if (dtype == THEIA_BF16) {
         if (n128 && c128) return launch_wgrad<bf16_t, 128, 128>(a, s);

@@ -1,0 +1,218 @@
+// Ping-pong NT implicit GEMM for the 256x256 tile (8 wave64 = two groups of four, one wave of each group per SIMD).
+//
+// The two wave groups run the same program ONE BARRIER APART, and the program alternates two kinds of segments:
+//     R(P): ds_read_b128 the operand fragments of phase P              |  M(P): 16 x v_mfma_f32_16x16x32_bf16
+// so whenever group 0 is in an M segment group 1 is in an R segment and vice versa: the matrix pipe of every SIMD is fed by
+// one wave while the SIMD's other wave fetches its next fragments (rocprofv3 on the lock-step kernels: 28 % MFMA busy, 42 %
+// of wave cycles parked in s_waitcnt/s_barrier).  Operands arrive by LDS-DMA (global_load_lds_dwordx4) into a 4-deep ring
+// of HALF k-tiles (32 bf16 / 16 f32 of k per row, 64-byte rows, source-side XOR swizzle as in gemm_ring.hip); two pieces of
+// half-tile h+3 are issued inside every M segment (behind MFMAs their issue cost is hidden) and only counted waits are used:
+//     end of R(2h+1):  s_waitcnt vmcnt(6)  -> half-tile h+1 has landed (h+2 and the first half of h+3 stay in flight)
+// Phase P = 2h + sub works on half-tile h: sub 0 reads the B fragments (4, kept for both phases) and the A fragments of the
+// wave's upper 64 rows, sub 1 the A fragments of its lower 64 rows.
+//
+// Hazards (interval k = time between barrier k and k+1; group 0 runs segment k in interval k, group 1 segment k-1):
+//   WAR  ring slot (h+3)&3 = (h-1)&3 is refilled from M(2h) on (interval >= 4h+1); its last readers are R(2h-1) of group 0
+//        (interval 4h-2) and of group 1 (interval 4h-1), both closed by s_waitcnt lgkmcnt(0) before their barrier.
+//   RAW  half-tile h+3 is first read in interval 4h+12 (group 0, R(2h+6)); every wave has waited for its own pieces of it at
+//        the end of its R(2h+5) (interval 4h+10 / 4h+11), i.e. before barrier 4h+12.
+#include "gemm_tile.h"
+
+__device__ uint4 g_pp_zero_page[16];
+
+__device__ __forceinline__ int pp_f(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+
+template <typename T>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t p) {
+    constexpr int BM = 256, BN = 256, WAVES_N = 4;
+    constexpr int NSTAGE = 4;
+    constexpr int HKT = 64 / (int)sizeof(T);
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int WM = 128, WN = 64, FM = 8, FN = 4;
+    constexpr int SRP = 128;                    // rows staged per pass (512 threads x 16 B = 128 rows of 64 B)
+    constexpr int NPA = BM / SRP, NPB = BN / SRP;
+    constexpr int LPH = NPA + NPB;              // 4 LDS-DMA pieces per thread per half-tile
+    constexpr int STAGE = (BM + BN) * 64;
+    static_assert(LPH == 4, "schedule below assumes 2 pieces per M segment");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;  // wm = wave group (0: waves 0-3, 1: waves 4-7)
+    const int ugroup = uwave >> 2;
+    const theia_rowmap_t& mp = p.map;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile = gt_xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.a);
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.w);
+
+    const int st_chunk = tid & 3, st_row = tid >> 2;
+    const int lchunk = st_chunk ^ pp_f(st_row);
+    const int R = mp.rows_h * mp.rows_w;
+    int64_t a_base[NPA];
+    int a_iy0[NPA], a_ix0[NPA];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int m = m0 + st_row + SRP * i;
+        if (m < p.M) {
+            const int img = m / R, rem = m - img * R;
+            const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
+            a_base[i] = (int64_t)img * mp.in_batch_stride + mp.in_offset;
+            a_iy0[i] = ry * mp.in_sy;
+            a_ix0[i] = rx * mp.in_sx;
+        } else {
+            a_base[i] = 0;
+            a_iy0[i] = -(1 << 28);
+            a_ix0[i] = 0;
+        }
+    }
+    int64_t w_base[NPB];
+    bool w_ok[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int n = n0 + st_row + SRP * i;
+        w_ok[i] = n < p.N;
+        w_base[i] = (int64_t)n * p.ldw;
+    }
+
+    gt_f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = (gt_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nh = (p.K + HKT - 1) / HKT;   // host guarantees K % HKT == 0 for this kernel
+    const uint64_t zp = reinterpret_cast<uint64_t>(g_pp_zero_page);
+    // Per-tap source pointers of this thread's LDS-DMA pieces (recomputed only when the prefetch stream enters a new tap, a
+    // wave-uniform event): inside the M segments a piece costs one masked 64-bit add + the LDS-DMA issue.
+    uint64_t src_ptr[LPH], src_msk[LPH];
+    auto set_tap = [&](int tap) {
+        const int dy = mp.dy[tap], dx = mp.dx[tap];
+        const int64_t wcol = (int64_t)mp.wslot[tap] * mp.in_c + lchunk * EPC;
+#pragma unroll
+        for (int q = 0; q < NPA; ++q) {
+            const int iy = a_iy0[q] + dy, ix = a_ix0[q] + dx;
+            const bool ok = (iy >= 0) & (iy < mp.in_h) & (ix >= 0) & (ix < mp.in_w);
+            const uint64_t pa = reinterpret_cast<uint64_t>(A + a_base[q] + (int64_t)(iy * mp.in_w + ix) * mp.in_c + lchunk * EPC);
+            const uint64_t msk = 0ull - (uint64_t)ok;
+            src_ptr[q] = (pa & msk) | (zp & ~msk);
+            src_msk[q] = msk;
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const uint64_t pw = reinterpret_cast<uint64_t>(W + w_base[i] + wcol);
+            const uint64_t msk = 0ull - (uint64_t)w_ok[i];
+            src_ptr[NPA + i] = (pw & msk) | (zp & ~msk);
+            src_msk[NPA + i] = msk;
+        }
+    };
+    auto issue_piece = [&](int q, uint64_t coff, char* sa, char* sb) {
+        const uint64_t src = src_ptr[q] + (coff & src_msk[q]);
+        char* dst = q < NPA ? sa + q * (SRP * 64) : sb + (q - NPA) * (SRP * 64);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    const int hpt = mp.in_c / HKT;  // half-tiles per tap
+    int cur_tap = 0, next_tap_h = hpt;  // prefetch stream state: tap of half-tile hp, first half-tile of the next tap
+    set_tap(0);
+    // prologue: half-tiles 0..2 (clamped for very short K; the duplicates are never read)
+#pragma unroll
+    for (int h = 0; h < NSTAGE - 1; ++h) {
+        const int hp = min(h, nh - 1);
+        if (hp >= next_tap_h) {
+            ++cur_tap;
+            next_tap_h += hpt;
+            set_tap(cur_tap);
+        }
+        const uint64_t coff = (uint64_t)(hp - cur_tap * hpt) * 64;
+        char* sa = smem + h * STAGE + uwave * (16 * 64);
+#pragma unroll
+        for (int q = 0; q < LPH; ++q) issue_piece(q, coff, sa, sa + BM * 64);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPH) : "memory");  // half-tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ugroup == 1) {  // group 1 runs one barrier behind group 0
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    const int frow = lane & 15, fg = lane >> 4;
+    uint4 fb[FN];
+    for (int h = 0; h < nh; ++h) {
+        const int hp = min(h + NSTAGE - 1, nh - 1);  // half-tile prefetched during this iteration (clamped at the tail)
+        if (hp >= next_tap_h) {                       // wave-uniform, once per in_c/HKT iterations
+            ++cur_tap;
+            next_tap_h += hpt;
+            set_tap(cur_tap);
+        }
+        const uint64_t coff = (uint64_t)(hp - cur_tap * hpt) * 64;
+        char* na = smem + ((h + NSTAGE - 1) & (NSTAGE - 1)) * STAGE + uwave * (16 * 64);
+        char* nb = na + BM * 64;
+        const char* sa = smem + (h & (NSTAGE - 1)) * STAGE;
+        const char* sb = sa + BM * 64;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            // ---------------- R(2h + sub)
+            uint4 fa[4];
+            if (sub == 0) {
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    const int row = wn * WN + i * 16 + frow;
+                    fb[i] = *reinterpret_cast<const uint4*>(sb + row * 64 + ((fg ^ pp_f(row)) << 4));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wm * WM + (sub * 4 + j) * 16 + frow;
+                fa[j] = *reinterpret_cast<const uint4*>(sa + row * 64 + ((fg ^ pp_f(row)) << 4));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (sub == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- M(2h + sub): 16 MFMAs + 2 LDS-DMA pieces of half-tile h+3
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < FN; ++i) GtMma<T>::run(acc[i][sub * 4 + j], fb[i], fa[j]);
+                if (j == 0) issue_piece(sub * 2, coff, na, nb);
+                if (j == 2) issue_piece(sub * 2 + 1, coff, na, nb);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (ugroup == 0) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the clamped tail prefetches before LDS is reused
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    float* ep = reinterpret_cast<float*>(smem) + wave * (64 * (WN + 4));
+    gt_epilogue<T, WM, WN>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
+}
+
+int theia_gemm_nt_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t stream) {
+    constexpr int stage_bytes = 4 * (256 + 256) * 64;
+    constexpr int ep_bytes = 8 * 64 * (64 + 4) * 4;
+    constexpr int lds = stage_bytes > ep_bytes ? stage_bytes : ep_bytes;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int tiles = cdiv_i(a->M, 256) * cdiv_i(a->N, 256);
+    if (dtype == THEIA_BF16) hipLaunchKernelGGL(gemm_nt_pp_kernel<bf16_t>, dim3(tiles), dim3(512), lds, stream, *a);
+    else hipLaunchKernelGGL(gemm_nt_pp_kernel<float>, dim3(tiles), dim3(512), lds, stream, *a);
+    THEIA_CHECK_LAUNCH("theia_gemm_nt(pp)");
+    return THEIA_OK;
+}

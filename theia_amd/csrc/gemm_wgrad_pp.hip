@@ -1,0 +1,197 @@
+// Ping-pong weight-gradient GEMM (bf16):  slab[s][n][wslot*in_c + c] = sum_{m in split s} dY[m, n] * A[m, (tap, c)]
+//
+// Same two-wave-group schedule, 4-deep LDS-DMA ring and counted waits as gemm_pp.hip (read that header first); what differs:
+//   * the contraction runs over ROWS m, so one ring slot holds 32 rows of dY (256 n-columns) and 32 rows of the gathered
+//     activation (256 c-columns of one tap): [32][512 B] + [32][512 B];
+//   * both MFMA operands are therefore m-major in LDS and their fragments are fetched with the transposing read
+//     ds_read_b64_tr_b16 (two per fragment: rows 4g..4g+3 and 16+4g..16+4g+3 -- the k-slot permutation both operands share);
+//   * bank conflicts: a half-wave's transposing read touches 8 rows x 32 B of one column block, so the 32-byte block index is
+//     XORed with (row & 7) inside each 256-byte segment; LDS-DMA writes lane-linearly, hence the swizzle is applied to the
+//     source column of each lane (each lane owns a fixed column for the whole kernel);
+//   * each thread stages 2 rows per 32-row step (both operands); the (image, y, x) decode of a row is kept incrementally
+//     (m advances by 32: float-reciprocal wrap, no integer division) and is recomputed for one row per M segment;
+//   * rows past the end of the split (or of M) read a page of zeros, so the tail needs no special case.
+// Output tile 256 (c) x 256 (n) per workgroup; 8 waves, each 128 (c) x 64 (n); accumulators go straight to the f32 slab.
+#include "gemm_tile.h"
+
+typedef __attribute__((ext_vector_type(4))) short wp_s16x4;
+
+__device__ uint4 g_wp_zero_page[16];
+
+__device__ __forceinline__ uint4 wp_tr_frag(const char* __restrict__ part, int lb, int lane) {
+    const int q = lane & 15, g = lane >> 4;
+    const int row = g * 4 + (q >> 2);
+    const int pb = (lb & 8) | ((lb & 7) ^ (row & 7));
+    const char* p = part + row * 512 + pb * 32 + (q & 3) * 8;
+    const wp_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wp_s16x4*)(p));
+    const wp_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wp_s16x4*)(p + 16 * 512));
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+
+__global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_args_t p) {
+    constexpr int NSTAGE = 4, MS = 32, ROWB = 512, PART = MS * ROWB, STAGE = 2 * PART;
+    constexpr int FM = 8, FN = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int ugroup = uwave >> 2;
+    const int wm = wave >> 2, wn = wave & 3;   // wm: which 128 c-columns (= wave group), wn: which 64 n-columns
+    const theia_rowmap_t& mp = p.map;
+    const int tiles_n = (p.N + 255) / 256;
+    const int tiles_c = mp.in_c / 256;
+    const int ntile = tiles_n * mp.ntaps * tiles_c;
+    const int tile = blockIdx.x % ntile, split = blockIdx.x / ntile;
+    const int tn = tile % tiles_n, tk = tile / tiles_n;
+    const int tap = tk / tiles_c, c0 = (tk - tap * tiles_c) * 256, n0 = tn * 256;
+    const int dy = mp.dy[tap], dx = mp.dx[tap];
+
+    const int nsteps = (p.M + MS - 1) / MS;
+    const int per = (nsteps + p.splits - 1) / p.splits;
+    const int s_begin = split * per;
+    const int s_end = min(nsteps, s_begin + per);
+    const int nh = max(0, s_end - s_begin);
+    const int m_limit = min(p.M, s_end * MS);
+
+    const bf16_t* __restrict__ DY = reinterpret_cast<const bf16_t*>(p.dy);
+    const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.a);
+    const uint64_t zp = reinterpret_cast<uint64_t>(g_wp_zero_page);
+
+    // ---- this thread's staging column (fixed) and its two rows' decode state
+    const int srow = tid >> 5, s16 = tid & 31;
+    const int pb = s16 >> 1;
+    const int lb = (pb & 8) | ((pb & 7) ^ (srow & 7));
+    const int col = (lb * 2 + (s16 & 1)) * 8;            // element column inside the 256-wide tile
+    const bool n_ok = n0 + col < p.N;
+    const float rcpW = 1.0f / (float)mp.rows_w, rcpH = 1.0f / (float)mp.rows_h;
+    int st_m[2], st_img[2], st_ry[2], st_rx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = s_begin * MS + srow + 16 * i;
+        const int R = mp.rows_h * mp.rows_w;
+        st_m[i] = m;
+        st_img[i] = m / R;
+        const int rem = m - st_img[i] * R;
+        st_ry[i] = rem / mp.rows_w;
+        st_rx[i] = rem - st_ry[i] * mp.rows_w;
+    }
+    // issue the dY piece and the activation piece of row i for the current half-step, then advance the row by 32
+    auto issue_row = [&](int i, char* slot) {
+        const bool mok = st_m[i] < m_limit;
+        const int64_t oy = (int64_t)st_img[i] * mp.out_batch_stride + mp.out_offset +
+                           (int64_t)((st_ry[i] * mp.out_sy + mp.out_y0) * mp.out_w + st_rx[i] * mp.out_sx + mp.out_x0) * p.ldo + n0 + col;
+        const int iy = st_ry[i] * mp.in_sy + dy, ix = st_rx[i] * mp.in_sx + dx;
+        const bool xok = mok & (iy >= 0) & (iy < mp.in_h) & (ix >= 0) & (ix < mp.in_w);
+        const int64_t ox = (int64_t)st_img[i] * mp.in_batch_stride + mp.in_offset + (int64_t)(iy * mp.in_w + ix) * mp.in_c + c0 + col;
+        const uint64_t my = 0ull - (uint64_t)(mok & n_ok), mx = 0ull - (uint64_t)xok;
+        const uint64_t sy = (reinterpret_cast<uint64_t>(DY + oy) & my) | (zp & ~my);
+        const uint64_t sx = (reinterpret_cast<uint64_t>(A + ox) & mx) | (zp & ~mx);
+        char* dst = slot + (16 * i + uwave * 2) * ROWB;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sy, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx, (__attribute__((address_space(3))) void*)(dst + PART), 16, 0, 0);
+        // advance: m += 32  ->  (rx, ry, img) with float-reciprocal wraps (operands < 2^12, one correction each)
+        st_m[i] += MS;
+        int rx = st_rx[i] + MS;
+        int q = (int)((float)rx * rcpW);
+        rx -= q * mp.rows_w;
+        if (rx >= mp.rows_w) { rx -= mp.rows_w; ++q; }
+        if (rx < 0) { rx += mp.rows_w; --q; }
+        int ry = st_ry[i] + q;
+        int q2 = (int)((float)ry * rcpH);
+        ry -= q2 * mp.rows_h;
+        if (ry >= mp.rows_h) { ry -= mp.rows_h; ++q2; }
+        if (ry < 0) { ry += mp.rows_h; --q2; }
+        st_rx[i] = rx;
+        st_ry[i] = ry;
+        st_img[i] += q2;
+    };
+
+    gt_f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = (gt_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // prologue: half-steps 0..2 (rows past the split end read zeros)
+#pragma unroll
+    for (int h = 0; h < NSTAGE - 1; ++h) {
+        issue_row(0, smem + h * STAGE);
+        issue_row(1, smem + h * STAGE);
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // half-step 0 landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ugroup == 1) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    uint4 fb[FN];
+    for (int h = 0; h < nh; ++h) {
+        char* nslot = smem + ((h + NSTAGE - 1) & (NSTAGE - 1)) * STAGE;
+        const char* sy = smem + (h & (NSTAGE - 1)) * STAGE;  // dY part; activation part follows
+        const char* sx = sy + PART;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            // ---------------- R(2h + sub)
+            uint4 fa[4];
+            if (sub == 0) {
+#pragma unroll
+                for (int i = 0; i < FN; ++i) fb[i] = wp_tr_frag(sy, wn * 4 + i, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fa[j] = wp_tr_frag(sx, wm * 8 + sub * 4 + j, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (sub == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- M(2h + sub): 16 MFMAs + row `sub` of half-step h+3
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < FN; ++i) GtMma<bf16_t>::run(acc[i][sub * 4 + j], fa[j], fb[i]);
+                if (j == 0) issue_row(sub, nslot);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (ugroup == 0) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // lane holds n = nf*16 + (lane&15), c = kf*16 + (lane>>4)*4 .. +4  ->  one float4 per fragment
+    const int64_t krow = (int64_t)p.kslots * mp.in_c;
+    float* slab = p.slabs + (int64_t)split * p.N * krow;
+    const int q = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + q;
+        if (n >= p.N) continue;
+        float* drow = slab + (int64_t)n * krow + (int64_t)mp.wslot[tap] * mp.in_c + c0 + wm * 128 + g * 4;
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+            *reinterpret_cast<float4*>(drow + j * 16) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+}
+
+// bf16 only; requires in_c % 256 == 0.  Returns THEIA_ERR_UNSUPPORTED when the shape does not qualify.
+int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) {
+    if (a->map.in_c % 256 != 0 || a->N < 128) return THEIA_ERR_UNSUPPORTED;
+    constexpr int lds = 4 * 2 * 32 * 512;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int tiles = cdiv_i(a->N, 256) * a->map.ntaps * (a->map.in_c / 256);
+    hipLaunchKernelGGL(gemm_wgrad_pp_kernel, dim3(tiles * a->splits), dim3(512), lds, stream, *a);
+    THEIA_CHECK_LAUNCH("theia_gemm_wgrad(pp)");
+    return THEIA_OK;
+}
