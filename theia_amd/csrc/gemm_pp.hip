@@ -7,18 +7,29 @@
 // of wave cycles parked in s_waitcnt/s_barrier).  Operands arrive by LDS-DMA (global_load_lds_dwordx4) into a 4-deep ring
 // of HALF k-tiles (32 bf16 / 16 f32 of k per row, 64-byte rows, source-side XOR swizzle as in gemm_ring.hip); two pieces of
 // half-tile h+3 are issued inside every M segment (behind MFMAs their issue cost is hidden) and only counted waits are used:
-//     end of R(2h+1):  s_waitcnt vmcnt(6)  -> half-tile h+1 has landed (h+2 and the first half of h+3 stay in flight)
-// Phase P = 2h + sub works on half-tile h: sub 0 reads the B fragments (4, kept for both phases) and the A fragments of the
-// wave's upper 64 rows, sub 1 the A fragments of its lower 64 rows.
+//     end of R(h):  s_waitcnt vmcnt(4)  -> half-tile h+1 has landed (h+2 stays in flight, h+3 is issued in M(h))
+// One phase per half-tile: R(h) reads 4 B + 8 A fragments, M(h) issues 32 MFMAs (cycle trace, tools/pp_trace.hip: with 16
+// MFMAs per phase the R segment + two barriers, not the MFMAs, set the interval).
 //
 // Hazards (interval k = time between barrier k and k+1; group 0 runs segment k in interval k, group 1 segment k-1):
-//   WAR  ring slot (h+3)&3 = (h-1)&3 is refilled from M(2h) on (interval >= 4h+1); its last readers are R(2h-1) of group 0
-//        (interval 4h-2) and of group 1 (interval 4h-1), both closed by s_waitcnt lgkmcnt(0) before their barrier.
-//   RAW  half-tile h+3 is first read in interval 4h+12 (group 0, R(2h+6)); every wave has waited for its own pieces of it at
-//        the end of its R(2h+5) (interval 4h+10 / 4h+11), i.e. before barrier 4h+12.
+//   WAR  ring slot (h+3)&3 = (h-1)&3 is refilled from M(h) on (interval >= 2h+1); its last readers are R(h-1) of group 0
+//        (interval 2h-2) and of group 1 (interval 2h-1), both closed by s_waitcnt lgkmcnt(0) before their barrier.
+//   RAW  half-tile h+1 is first read in interval 2h+2 (group 0, R(h+1)); every wave has waited for its own pieces of it at
+//        the end of its R(h) (interval 2h / 2h+1), i.e. before barrier 2h+2.
 #include "gemm_tile.h"
 
 __device__ uint4 g_pp_zero_page[16];
+
+// Optional cycle trace (tools/pp_trace.hip builds this file with -DPP_TRACE): s_memtime stamps of block 0 at the segment
+// boundaries of iterations PP_TRACE_H0 .. PP_TRACE_H0+3, one row per wave.  Compiled out of the library.
+#ifdef PP_TRACE
+__device__ unsigned long long g_pp_trace[8][4][2][5];
+#define PP_STAMP(k)                                                                                  \
+    if (blockIdx.x == 0 && h >= PP_TRACE_H0 && h < PP_TRACE_H0 + 4 && lane == 0)                      \
+        g_pp_trace[wave][h - PP_TRACE_H0][0][k] = __builtin_readcyclecounter();
+#else
+#define PP_STAMP(k)
+#endif
 
 __device__ __forceinline__ int pp_f(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
@@ -152,38 +163,39 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         char* nb = na + BM * 64;
         const char* sa = smem + (h & (NSTAGE - 1)) * STAGE;
         const char* sb = sa + BM * 64;
+        {
+            // ---------------- R(h): 12 fragment reads
+            PP_STAMP(0)
+            uint4 fa[FM];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            // ---------------- R(2h + sub)
-            uint4 fa[4];
-            if (sub == 0) {
-#pragma unroll
-                for (int i = 0; i < FN; ++i) {
-                    const int row = wn * WN + i * 16 + frow;
-                    fb[i] = *reinterpret_cast<const uint4*>(sb + row * 64 + ((fg ^ pp_f(row)) << 4));
-                }
+            for (int i = 0; i < FN; ++i) {
+                const int row = wn * WN + i * 16 + frow;
+                fb[i] = *reinterpret_cast<const uint4*>(sb + row * 64 + ((fg ^ pp_f(row)) << 4));
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wm * WM + (sub * 4 + j) * 16 + frow;
+            for (int j = 0; j < FM; ++j) {
+                const int row = wm * WM + j * 16 + frow;
                 fa[j] = *reinterpret_cast<const uint4*>(sa + row * 64 + ((fg ^ pp_f(row)) << 4));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (sub == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6) : "memory");
+            PP_STAMP(1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPH) : "memory");  // half-tile h+1 landed; h+2 may still be in flight
             __builtin_amdgcn_sched_barrier(0);
+            PP_STAMP(2)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            // ---------------- M(2h + sub): 16 MFMAs + 2 LDS-DMA pieces of half-tile h+3
+            // ---------------- M(h): 32 MFMAs + the 4 LDS-DMA pieces of half-tile h+3
+            PP_STAMP(3)
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < FM; ++j) {
 #pragma unroll
-                for (int i = 0; i < FN; ++i) GtMma<T>::run(acc[i][sub * 4 + j], fb[i], fa[j]);
-                if (j == 0) issue_piece(sub * 2, coff, na, nb);
-                if (j == 2) issue_piece(sub * 2 + 1, coff, na, nb);
+                for (int i = 0; i < FN; ++i) GtMma<T>::run(acc[i][j], fb[i], fa[j]);
+                if ((j & 1) == 0) issue_piece(j >> 1, coff, na, nb);
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            PP_STAMP(4)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -76,6 +76,28 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
     if (p.bias != nullptr && n < p.N) load8(p.bias + n, bias8);
 #pragma unroll
     for (int hf = 0; hf < WM / EPH; ++hf) {
+        // (1) issue every global read of this pass group first (residual / aux / row table): their latency then overlaps
+        //     the LDS round trip instead of being paid once per row pass
+        constexpr int NPS = EPH / RPP;
+        int64_t off[NPS];
+        bool live[NPS];
+        uint4 rpre[NPS];  // prefetched aux_in (ACT_MUL_*) or, otherwise, residual rows (bf16 path)
+        const bool want_aux = p.act == THEIA_ACT_MUL_DGELU || p.act == THEIA_ACT_MUL_DRELU;
+        const T* __restrict__ PRE = want_aux ? AUXI : RES;
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+            const int row = ps * RPP + lane / LPR;
+            const int m = m_wave0 + hf * EPH + row;
+            live[ps] = (m < p.M) && (n < p.N);
+            const int mm = live[ps] ? m : 0;
+            const int img = mm / R, rem = mm - img * R;
+            const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
+            off[ps] = (int64_t)img * mp.out_batch_stride + mp.out_offset +
+                      (int64_t)((ry * mp.out_sy + mp.out_y0) * mp.out_w + rx * mp.out_sx + mp.out_x0) * p.ldo + (live[ps] ? n : 0);
+            rpre[ps] = make_uint4(0, 0, 0, 0);
+            if (sizeof(T) == 2 && PRE != nullptr && live[ps]) rpre[ps] = *reinterpret_cast<const uint4*>(PRE + off[ps]);
+        }
+        // (2) accumulators -> wave-private LDS tile
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -86,24 +108,35 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
             }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
+        // (3) row-contiguous passes
 #pragma unroll
-        for (int ps = 0; ps < EPH / RPP; ++ps) {
+        for (int ps = 0; ps < NPS; ++ps) {
             const int row = ps * RPP + lane / LPR;
-            const int m = m_wave0 + hf * EPH + row;
-            if (m >= p.M || n >= p.N) continue;
+            if (!live[ps]) continue;
+            const int64_t o = off[ps];
             float v[8];
             load8(ep + row * EP_PITCH + col, v);
-            const int img = m / R, rem = m - img * R;
-            const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
-            const int64_t o = (int64_t)img * mp.out_batch_stride + mp.out_offset +
-                              (int64_t)((ry * mp.out_sy + mp.out_y0) * mp.out_w + rx * mp.out_sx + mp.out_x0) * p.ldo + n;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += bias8[j];
             if (p.rowtab != nullptr) {
+                const int m = m_wave0 + hf * EPH + row;
                 float t8[8];
                 load8(p.rowtab + (int64_t)(m % p.rowtab_period) * p.N + n, t8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += t8[j];
+            }
+            float a8[8];
+            if (want_aux) {
+                if (sizeof(T) == 2) {
+                    const uint32_t w4[4] = {rpre[ps].x, rpre[ps].y, rpre[ps].z, rpre[ps].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        a8[2 * j] = __uint_as_float(w4[j] << 16);
+                        a8[2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u);
+                    }
+                } else {
+                    load8(AUXI + o, a8);
+                }
             }
             if (p.act == THEIA_ACT_GELU) {
                 if (AUXO != nullptr) store8(AUXO + o, v);
@@ -113,19 +146,24 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
             } else if (p.act == THEIA_ACT_MUL_DGELU) {
-                float a8[8];
-                load8(AUXI + o, a8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] *= gt_gelu_grad<T>(a8[j]);
             } else if (p.act == THEIA_ACT_MUL_DRELU) {
-                float a8[8];
-                load8(AUXI + o, a8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = a8[j] > 0.f ? v[j] : 0.f;
             }
             if (RES != nullptr) {
                 float r8[8];
-                load8(RES + o, r8);
+                if (sizeof(T) == 2 && !want_aux) {
+                    const uint32_t w4[4] = {rpre[ps].x, rpre[ps].y, rpre[ps].z, rpre[ps].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        r8[2 * j] = __uint_as_float(w4[j] << 16);
+                        r8[2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u);
+                    }
+                } else {
+                    load8(RES + o, r8);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += r8[j];
             }

@@ -9,7 +9,7 @@
 //     XORed with (row & 7) inside each 256-byte segment; LDS-DMA writes lane-linearly, hence the swizzle is applied to the
 //     source column of each lane (each lane owns a fixed column for the whole kernel);
 //   * each thread stages 2 rows per 32-row step (both operands); the (image, y, x) decode of a row is kept incrementally
-//     (m advances by 32: float-reciprocal wrap, no integer division) and is recomputed for one row per M segment;
+//     (m advances by 32: float-reciprocal wrap, no integer division) inside the M segments;
 //   * rows past the end of the split (or of M) read a page of zeros, so the tail needs no special case.
 // Output tile 256 (c) x 256 (n) per workgroup; 8 waves, each 128 (c) x 64 (n); accumulators go straight to the f32 slab.
 #include "gemm_tile.h"
@@ -131,28 +131,26 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
         char* nslot = smem + ((h + NSTAGE - 1) & (NSTAGE - 1)) * STAGE;
         const char* sy = smem + (h & (NSTAGE - 1)) * STAGE;  // dY part; activation part follows
         const char* sx = sy + PART;
+        {
+            // ---------------- R(h): 12 transposed fragments (24 ds_read_b64_tr_b16)
+            uint4 fa[FM];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            // ---------------- R(2h + sub)
-            uint4 fa[4];
-            if (sub == 0) {
+            for (int i = 0; i < FN; ++i) fb[i] = wp_tr_frag(sy, wn * 4 + i, lane);
 #pragma unroll
-                for (int i = 0; i < FN; ++i) fb[i] = wp_tr_frag(sy, wn * 4 + i, lane);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fa[j] = wp_tr_frag(sx, wm * 8 + sub * 4 + j, lane);
+            for (int j = 0; j < FM; ++j) fa[j] = wp_tr_frag(sx, wm * 8 + j, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (sub == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // half-step h+1 landed; h+2 may still be in flight
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            // ---------------- M(2h + sub): 16 MFMAs + row `sub` of half-step h+3
+            // ---------------- M(h): 32 MFMAs + both rows of half-step h+3
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < FM; ++j) {
 #pragma unroll
-                for (int i = 0; i < FN; ++i) GtMma<bf16_t>::run(acc[i][sub * 4 + j], fa[j], fb[i]);
-                if (j == 0) issue_row(sub, nslot);
+                for (int i = 0; i < FN; ++i) GtMma<bf16_t>::run(acc[i][j], fa[j], fb[i]);
+                if (j == 0) issue_row(0, nslot);
+                if (j == 4) issue_row(1, nslot);
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);

@@ -1,0 +1,38 @@
+// Standalone cycle-trace harness for the ping-pong GEMM kernel (not part of libtheia_hip.so):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPP_TRACE -DPP_TRACE_H0=40 tools/pp_trace.hip -o build/pp_trace && build/pp_trace
+// Prints, for block 0 and every wave, the s_memtime stamps at: R start, ds_reads done, vmcnt done, M start (after the
+// barrier), M end -- for four consecutive half-tiles.
+#include <stdarg.h>
+#include <vector>
+#include "../theia_amd/csrc/gemm_pp.hip"
+
+void theia_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
+
+int main() {
+    const int M = 32768, N = 768, K = 6912;
+    bf16_t *a, *w, *o;
+    hipMalloc(&a, (size_t)M * K * 2); hipMalloc(&w, (size_t)N * K * 2); hipMalloc(&o, (size_t)M * N * 2);
+    std::vector<uint16_t> ha((size_t)M * 64), hw((size_t)N * K);
+    for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0x3c00 + (i * 2654435761u >> 20 & 0x1ff);
+    hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+    for (size_t r = 0; r < (size_t)M * K; r += hw.size()) hipMemcpy(a + r, hw.data(), std::min(hw.size(), (size_t)M * K - r) * 2, hipMemcpyHostToDevice);
+    theia_gemm_args_t g; memset(&g, 0, sizeof(g));
+    g.a = a; g.w = w; g.out = o; g.M = M; g.N = N; g.K = K; g.ldw = K; g.ldo = N;
+    g.map.ntaps = 1; g.map.rows_h = g.map.rows_w = g.map.in_h = g.map.in_w = g.map.out_w = 1; g.map.in_sy = g.map.in_sx = 1;
+    g.map.out_sy = g.map.out_sx = 1; g.map.in_c = K; g.map.in_batch_stride = K; g.map.out_batch_stride = N;
+    for (int it = 0; it < 3; ++it) theia_gemm_nt_pp_launch(&g, THEIA_BF16, 0);
+    hipDeviceSynchronize();
+    unsigned long long t[8][4][2][5];
+    hipMemcpyFromSymbol(t, HIP_SYMBOL(g_pp_trace), sizeof(t));
+    const unsigned long long t0 = t[0][0][0][0];
+    for (int wv = 0; wv < 8; ++wv) {
+        printf("wave %d:", wv);
+        for (int h = 0; h < 4; ++h)
+            for (int s = 0; s < 2; ++s) {
+                printf(" |");
+                for (int k = 0; k < 5; ++k) printf(" %5lld", (long long)(t[wv][h][s][k] - t0));
+            }
+        printf("\n");
+    }
+    return 0;
+}
