@@ -15,6 +15,7 @@ launches on the current stream -- there is no torch math and no CPU fallback on 
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -78,6 +79,46 @@ def to_uint8_batch(x: Any) -> Tuple[torch.Tensor, bool]:
         raise NotImplementedError(f"{hh}x{ww} input: resize / crop / pos-emb interpolation are outside the hot path "
                                   f"(SURVEY.md sec. 8f-3); feed {IMAGE}x{IMAGE} images")
     return x.contiguous(), channels_last
+
+
+class _SideQueue:
+    """A second HIP stream (+ its own scratch) for work whose results are only needed at the end of backward.
+
+    ``run(fn, *tensors)`` enqueues ``fn`` behind everything issued so far on the current stream; the tensors it reads are
+    pinned with ``record_stream`` so the caching allocator does not recycle them early; ``join()`` makes the current
+    stream wait for the queue.  With ``enabled=False`` everything runs inline (A/B switch THEIA_SIDE_STREAM=0)."""
+
+    def __init__(self, device, enabled: bool = True):
+        self.device = device
+        self.enabled = enabled
+        self.stream = torch.cuda.Stream(device=device) if enabled else None
+        self.ws: Optional[torch.Tensor] = None
+        self._dirty = False
+
+    def ensure_ws(self, nfloats: int) -> None:
+        if self.ws is None or self.ws.numel() < nfloats:
+            self.join()
+            self.ws = torch.empty(max(nfloats, 1 << 20), dtype=torch.float32, device=self.device)
+
+    def run(self, fn, *tensors) -> None:
+        if not self.enabled:
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            fn()
+        for t in tensors:
+            t.record_stream(self.stream)
+        self._dirty = True
+
+    def join(self) -> None:
+        if self.enabled and self._dirty:
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            self._dirty = False
 
 
 class GradBucket:
@@ -184,6 +225,14 @@ class StudentEngine:
             self.bucket_ready_hook(b)
 
     # ------------------------------------------------------------------ small helpers
+    def _side_queue(self, device, nfloats: int) -> "_SideQueue":
+        q = getattr(self, "_sideq", None)
+        if q is None or q.device != device:
+            q = _SideQueue(device, enabled=os.environ.get("THEIA_SIDE_STREAM", "1") != "0")
+            self._sideq = q
+        q.ensure_ws(nfloats)
+        return q
+
     def ws(self, nfloats: int, device) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nfloats or self._ws.device != device:
             self._ws = torch.empty(max(nfloats, 1 << 20), dtype=torch.float32, device=device)
@@ -328,14 +377,17 @@ class StudentEngine:
                   N.lib().theia_colsum_workspace_bytes(b, NTOK * D) // 4,
                   max(ops.wgrad_splits(M, n_, k_) * n_ * k_ for n_, k_ in ((D, F), (F, D), (D, D), (D, 768))))
         ws = self.ws(wsz, dev)
+        side = self._side_queue(dev, wsz)
 
+        # weight / bias gradients only feed the optimizer: they run on a side HIP stream so that their workgroups fill the
+        # CUs left idle by the tail rounds and epilogues of the data-gradient chain on the main stream (and vice versa)
         def wgrad(dy, x, p):
             g, acc = self._grad(p)
-            ops.linear_wgrad(dy, x, g, acc, ws)
+            side.run(lambda: ops.linear_wgrad(dy, x, g, acc, side.ws), dy, x)
 
         def bgrad(dy, p):
             g, acc = self._grad(p)
-            ops.colsum(dy, g, acc, ws)
+            side.run(lambda: ops.colsum(dy, g, acc, side.ws), dy)
 
         hL, meanf, rstdf = saved["final"]
         gw, accw = self._grad(vit.layernorm.weight)
@@ -378,6 +430,7 @@ class StudentEngine:
             dh = ops.layernorm_bwd(da, h, L.layernorm_before.weight, mean1, rstd1, dh1, g1w, g1b, acc, ws)
             del da, dh1
             if i in group_lo:
+                side.join()
                 self._bucket_done(group_lo[i])
         # embeddings: h0[b, 0] = cls + pos[0];  h0[b, 1+p] = patches @ Wp^T + bias + pos[1+p]
         emb = vit.embeddings
@@ -397,6 +450,7 @@ class StudentEngine:
         slabs = ws[: splits * D * 768]
         ops.gemm_wgrad(dh, saved["patches"], slabs, Mp, D, D, 1, splits, rmap)
         ops.wgrad_reduce(slabs, splits, D, 1, 768, gpw, 768, 0, 1, acc)
+        side.join()
         self._bucket_done(vit_buckets[3])
 
     # ================================================================== translator heads
@@ -480,27 +534,35 @@ class StudentEngine:
             if dp.dtype != T:
                 raise TypeError(f"gradient dtype {dp.dtype} does not match the engine's compute dtype {T}")
 
+            side = self._side_queue(dev, max(conv_slabs, lin_slabs, N.lib().theia_colsum_workspace_bytes(b * s2 * s2, max(C, Ct)) // 4 + 64))
+
             def lin_grads(dy, x, mod):
                 if not train:
                     return
-                g, acc = self._grad(mod.weight)
-                ops.linear_wgrad(dy, x, g, acc, ws)
-                g, acc = self._grad(mod.bias)
-                ops.colsum(dy, g, acc, ws)
+                gw, accw = self._grad(mod.weight)
+                gb, accb = self._grad(mod.bias)
+
+                def task():
+                    ops.linear_wgrad(dy, x, gw, accw, side.ws)
+                    ops.colsum(dy, gb, accb, side.ws)
+                side.run(task, dy, x)
 
             def conv_grads(dy2d, x, mod, plan, mtot):
-                """dy2d [M_total, C] is the conv output gradient, x the conv input (flat NHWC)."""
+                """dy2d [M_total, C] is the conv output gradient, x the conv input (flat NHWC); side stream like the ViT's."""
                 if not train:
                     return
-                g, acc = self._grad(mod.bias)
-                ops.colsum(dy2d, g, acc, ws)
-                g, acc = self._grad(mod.weight)
-                splits = ops.wgrad_splits(mtot, C, 9 * C)
-                slabs = ws[: splits * C * 9 * C]
-                for rmap, mpi in plan.fwd:
-                    ops.gemm_wgrad(dy2d, x, slabs, b * mpi, C, C, 9, splits, rmap)
-                sn, ss, sc = plan.grad_strides
-                ops.wgrad_reduce(slabs, splits, C, 9, C, g, sn, ss, sc, acc)
+                gb, accb = self._grad(mod.bias)
+                gw, accw = self._grad(mod.weight)
+
+                def task():
+                    ops.colsum(dy2d, gb, accb, side.ws)
+                    splits = ops.wgrad_splits(mtot, C, 9 * C)
+                    slabs = side.ws[: splits * C * 9 * C]
+                    for rmap, mpi in plan.fwd:
+                        ops.gemm_wgrad(dy2d, x, slabs, b * mpi, C, C, 9, splits, rmap)
+                    sn, ss, sc = plan.grad_strides
+                    ops.wgrad_reduce(slabs, splits, C, 9, C, gw, sn, ss, sc, accw)
+                side.run(task, dy2d, x)
 
             def ln_bwd(dy, x, stats, idx, hw, relu_mask):
                 E = hw * hw * C
@@ -539,6 +601,7 @@ class StudentEngine:
             conv_dgrad(du1, oc[pf + "pad.wd"], self._plan("pad"), dz, resid=dz)
             del du1
             if train:
+                side.join()
                 self._bucket_done(bucket)
         return dz
 
