@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", f) for f in ("gemm.hip", "gemm_ring.hip", "gemm_pp.hip", "gemm_wgrad_pp.hip", "norm.hip", "misc.hip", "attention.hip", "attention_mfma.hip")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("gemm.hip", "gemm_pp.hip", "gemm_wgrad_pp.hip", "norm.hip", "misc.hip", "attention.hip", "attention_mfma.hip")]
 HDR = [os.path.join(HERE, "csrc", "common.h"), os.path.join(HERE, "csrc", "gemm_tile.h"), os.path.join(os.path.dirname(HERE), "include", "theia_hip.h")]
 OUT = os.path.join(HERE, "lib", "libtheia_hip.so")
 

@@ -1,18 +1,22 @@
-// MFMA GEMM kernels of the Theia hot path (gfx950 / CDNA4).
+// MFMA GEMM kernels of the Theia hot path (gfx950 / CDNA4) and the C-ABI dispatch of theia_gemm_nt / theia_gemm_wgrad.
 //
-//   gemm_nt_kernel    out[m,n] = epi( sum_k A[m,k] W[n,k] )    A gathered through a theia_rowmap_t (implicit
-//                     GEMM for Linear / Conv3x3 / ConvTranspose3x3 and every data-gradient)
-//   gemm_wgrad_kernel slab[s][n][k] = sum_{m in split s} dY[m,n] A[m,k]   (weight gradients, split over M)
+//   gemm_nt_kernel    out[m,n] = epi( sum_k A[m,k] W[n,k] )    A gathered through a theia_rowmap_t (implicit GEMM for
+//                     Linear / Conv3x3 / ConvTranspose3x3 and every data-gradient).  This file holds the 2-stage
+//                     kernel used for 128x128 / 128x64 tiles (f32 parity path, narrow N, small grids); 256x256 tiles go
+//                     to the ping-pong kernel of gemm_pp.hip.
+//   gemm_wgrad_kernel slab[s][n][k] = sum_{m in split s} dY[m,n] A[m,k]   (weight gradients, split over M): f32 path and
+//                     shapes the ping-pong kernel of gemm_wgrad_pp.hip does not take.
 //
-// Tiling: 256 threads = 4 wave64; LDS tiles are [rows][128 B] (64 bf16 / 32 f32 of K per row) with the 16-byte
-// chunk index XOR-swizzled by (row>>1)&7 so every ds_read_b128 fragment read is bank-conflict free; operands are
-// staged global -> registers -> LDS with the next tile's loads issued before the current tile's MFMAs.
+// 2-stage NT kernel: 256 threads = 4 wave64; LDS tiles are [rows][128 B] (64 bf16 / 32 f32 of K per row) filled by LDS-DMA
+// (global_load_lds_dwordx4, lane-linear destination) with the 16-byte chunk index XOR-swizzled by (row>>1)&7 on the SOURCE
+// side, so every ds_read_b128 fragment read is bank-conflict free; out-of-image taps / out-of-range rows read a page of
+// zeros (no predication, no divergent branches in the K loop).
 // bf16: v_mfma_f32_16x16x32_bf16 (one 16-byte chunk per lane = 8 consecutive k).
-// f32 : v_mfma_f32_16x16x4_f32, four per chunk (k order inside a tile is permuted identically for both operands,
-//       which leaves the sum unchanged up to fp32 association).
-// The MFMA is issued with the WEIGHT fragment as its A operand and the ACTIVATION fragment as its B operand, so a
-// lane ends up with 4 consecutive n for one m: the accumulator tile goes to LDS with ds_write_b128 and is re-read
-// row-contiguously, giving a fully vectorised epilogue (16-byte bias/residual/aux loads and output stores).
+// f32 : v_mfma_f32_16x16x4_f32, four per chunk (k order inside a tile is permuted identically for both operands, which
+//       leaves the sum unchanged up to fp32 association).
+// The MFMA is issued with the WEIGHT fragment as its A operand and the ACTIVATION fragment as its B operand, so a lane ends
+// up with 4 consecutive n for one m: the accumulator tile goes to LDS with ds_write_b128 and is re-read row-contiguously,
+// giving a fully vectorised epilogue (gemm_tile.h).
 #include "gemm_tile.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
@@ -49,12 +53,11 @@ __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + 
 // ================================================================================================
 // NT implicit GEMM
 // ================================================================================================
-int theia_gemm_nt_ring_launch(const theia_gemm_args_t* a, int dtype, int tile, hipStream_t stream);  // gemm_ring.hip
 int theia_gemm_nt_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t stream);               // gemm_pp.hip
 
-__device__ uint4 g_zero_page[16];  // 256 B of zeros: source of out-of-range operand chunks in the GLDS path
+__device__ uint4 g_zero_page[16];  // 256 B of zeros: source of out-of-range operand chunks
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GLDS>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const theia_gemm_args_t p) {
     constexpr int KT = 128 / (int)sizeof(T);   // k elements per LDS row
     constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
@@ -108,37 +111,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const t
         w_base[i] = (int64_t)n * p.ldw;
     }
 
-    uint4 ra[NPA], rb[NPB];
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * KT;
-        const int tap = k0 / mp.in_c;
-        const int c = k0 - tap * mp.in_c + st_chunk * EPC;
-        const bool cok = c < mp.in_c;
-        const int dy = mp.dy[tap], dx = mp.dx[tap];
-        const int64_t wcol = (int64_t)mp.wslot[tap] * mp.in_c + c;
-#pragma unroll
-        for (int i = 0; i < NPA; ++i) {
-            const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-            const bool ok = cok && iy >= 0 && iy < mp.in_h && ix >= 0 && ix < mp.in_w;
-            ra[i] = make_uint4(0, 0, 0, 0);
-            if (ok) ra[i] = *reinterpret_cast<const uint4*>(A + a_base[i] + (int64_t)(iy * mp.in_w + ix) * mp.in_c + c);
-        }
-#pragma unroll
-        for (int i = 0; i < NPB; ++i) {
-            rb[i] = make_uint4(0, 0, 0, 0);
-            if (cok && w_ok[i]) rb[i] = *reinterpret_cast<const uint4*>(W + w_base[i] + wcol);
-        }
-    };
-    auto store_tile = [&](int stage) {
-        char* sa = smem + stage * STAGE;
-        char* sb = sa + BM * 128;
-#pragma unroll
-        for (int i = 0; i < NPA; ++i) *reinterpret_cast<uint4*>(sa + swz_off(st_row + SRP * i, st_chunk)) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NPB; ++i) *reinterpret_cast<uint4*>(sb + swz_off(st_row + SRP * i, st_chunk)) = rb[i];
-    };
-
-    // GLDS staging: global_load_lds_dwordx4 writes LDS lane-linearly (wave-uniform base + lane*16), so the XOR swizzle is
+    // LDS-DMA staging: global_load_lds_dwordx4 writes LDS lane-linearly (wave-uniform base + lane*16), so the XOR swizzle is
     // applied on the SOURCE side: the lane that fills slot s of row r fetches logical chunk s ^ ((r>>1)&7).  Rows that are
     // out of range / taps that fall outside the image read a 256-byte page of zeros instead (no predication).
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
@@ -175,17 +148,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const t
         for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_v){0.f, 0.f, 0.f, 0.f};
 
     const int nkt = (p.K + KT - 1) / KT;
-    if constexpr (GLDS) {
-        issue_tile(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        load_tile(0);
-        store_tile(0);
-    }
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int frow = lane & 15, fg = lane >> 4;
-    if constexpr (GLDS) {
+    {
         // Branch-free single-block main loop: the source address of every LDS-DMA piece is selected with bit masks (no
         // divergent branches around the loads) and the last iteration simply re-fetches the last tile into the idle slot
         // instead of branching, so the compiler keeps the accumulators in place across iterations.
@@ -244,72 +212,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const t
             __syncthreads();
         }
     }
-    for (int kt = 0; !GLDS && kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) {
-            if constexpr (GLDS) issue_tile(kt + 1, cur ^ 1);
-            else load_tile(kt + 1);
-        }
-        const char* sa = smem + cur * STAGE;
-        const char* sb = sa + BM * 128;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            uint4 fa[FM], fb[FN];
-#pragma unroll
-            for (int j = 0; j < FM; ++j) fa[j] = *reinterpret_cast<const uint4*>(sa + swz_off(wm * WM + j * 16 + frow, kk * 4 + fg));
-#pragma unroll
-            for (int i = 0; i < FN; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz_off(wn * WN + i * 16 + frow, kk * 4 + fg));
-#pragma unroll
-            for (int i = 0; i < FN; ++i)
-#pragma unroll
-                for (int j = 0; j < FM; ++j) Mma<T>::run(acc[i][j], fb[i], fa[j]);
-        }
-        if constexpr (GLDS) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile has landed in LDS
-        } else {
-            if (kt + 1 < nkt) store_tile(cur ^ 1);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue (shared with the ring kernel): wave-private LDS round trip, 16-byte vector global accesses ----
+    // ---- epilogue (shared with the ping-pong kernel): wave-private LDS round trip, 16-byte vector global accesses ----
     float* ep = reinterpret_cast<float*>(smem) + wave * ((WM > 64 ? 64 : WM) * EP_PITCH);
     gt_epilogue<T, WM, WN>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
-// THEIA_GEMM_STAGING=regs selects the register-staged variant (global -> VGPR -> ds_write); default is the LDS-DMA one
-static bool use_glds() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("THEIA_GEMM_STAGING");
-        v = (e != nullptr && strcmp(e, "regs") == 0) ? 0 : 1;
-    }
-    return v == 1;
-}
-
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GLDS>
-static int launch_gemm_nt_v(const theia_gemm_args_t* a, hipStream_t stream) {
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_gemm_nt(const theia_gemm_args_t* a, hipStream_t stream) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int NTHR = 64 * WAVES_M * WAVES_N;
     constexpr int stage_bytes = 2 * (BM + BN) * 128;
     constexpr int ep_bytes = WAVES_M * WAVES_N * (WM > 64 ? 64 : WM) * (WN + 4) * 4;
     constexpr int lds = stage_bytes > ep_bytes ? stage_bytes : ep_bytes;
-    auto kern = gemm_nt_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS>;
+    auto kern = gemm_nt_kernel<T, BM, BN, WAVES_M, WAVES_N>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int tiles = cdiv_i(a->M, BM) * cdiv_i(a->N, BN);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHR), lds, stream, *a);
     THEIA_CHECK_LAUNCH("theia_gemm_nt");
     return THEIA_OK;
-}
-
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-static int launch_gemm_nt(const theia_gemm_args_t* a, hipStream_t stream) {
-    return use_glds() ? launch_gemm_nt_v<T, BM, BN, WAVES_M, WAVES_N, true>(a, stream)
-                      : launch_gemm_nt_v<T, BM, BN, WAVES_M, WAVES_N, false>(a, stream);
 }
 
 static int check_rowmap(const theia_rowmap_t& m, int kt, const char* who) {
@@ -364,15 +288,13 @@ extern "C" int theia_gemm_nt(const theia_gemm_args_t* a, int dtype, void* stream
     if (rc) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int tile = theia_gemm_nt_tile(a->M, a->N, dtype);
-    // 256x256 tiles default to the ping-pong kernel (gemm_pp.hip: two wave groups one barrier apart, 4-deep LDS-DMA ring);
-    // smaller tiles use the 2-stage kernel below.  THEIA_GEMM_KERNEL=std|ring|pp overrides (A/B measurements).
-    static int use_ring = -1;
-    if (use_ring < 0) {
+    // 256x256 tiles run the ping-pong kernel (gemm_pp.hip); THEIA_GEMM_KERNEL=std forces the 2-stage kernel (A/B runs)
+    static int use_pp = -1;
+    if (use_pp < 0) {
         const char* e = getenv("THEIA_GEMM_KERNEL");
-        use_ring = (e != nullptr && strcmp(e, "ring") == 0) ? 1 : (e != nullptr && strcmp(e, "std") == 0) ? 0 : 2;
+        use_pp = (e != nullptr && strcmp(e, "std") == 0) ? 0 : 1;
     }
-    if (use_ring == 1) return theia_gemm_nt_ring_launch(a, dtype, tile, s);
-    if (use_ring == 2 && tile == 256256 && a->K % (dtype == THEIA_BF16 ? 32 : 16) == 0) return theia_gemm_nt_pp_launch(a, dtype, s);  // ping-pong wave groups (gemm_pp.hip)
+    if (use_pp && tile == 256256 && a->K % (dtype == THEIA_BF16 ? 32 : 16) == 0) return theia_gemm_nt_pp_launch(a, dtype, s);
     if (dtype == THEIA_BF16) {
         if (tile == 256256) return launch_gemm_nt<bf16_t, 256, 256, 2, 4>(a, s);
         return tile == 128064 ? launch_gemm_nt<bf16_t, 128, 64, 2, 2>(a, s) : launch_gemm_nt<bf16_t, 128, 128, 2, 2>(a, s);
@@ -583,7 +505,7 @@ static int launch_wgrad(const theia_wgrad_args_t* a, hipStream_t stream) {
     auto kern = gemm_wgrad_kernel<T, BNN, BC>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int tiles = cdiv_i(a->N, BNN) * a->map.ntaps * (a->map.in_c / BC);
