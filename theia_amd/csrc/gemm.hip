@@ -91,8 +91,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const t
     for (int i = 0; i < NPA; ++i) {
         const int m = m0 + st_row + SRP * i;
         if (m < p.M) {
-            const int img = m / R, rem = m - img * R;
-            const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
+            int rem, rx;
+            const int img = gt_divmod(m, R, 1.0f / (float)R, rem);
+            const int ry = gt_divmod(rem, mp.rows_w, 1.0f / (float)mp.rows_w, rx);
             a_base[i] = (int64_t)img * mp.in_batch_stride + mp.in_offset;
             a_iy0[i] = ry * mp.in_sy;
             a_ix0[i] = rx * mp.in_sx;

@@ -24,11 +24,16 @@ __device__ uint4 g_pp_zero_page[16];
 // boundaries of iterations PP_TRACE_H0 .. PP_TRACE_H0+3, one row per wave.  Compiled out of the library.
 #ifdef PP_TRACE
 __device__ unsigned long long g_pp_trace[8][4][2][5];
+__device__ unsigned long long g_pp_phase[2][8][7];
+#define PP_PHASE(k)                                                                  \
+    if ((blockIdx.x & 255) == 0 && blockIdx.x < 512 && (threadIdx.x & 63) == 0)      \
+        g_pp_phase[blockIdx.x >> 8][threadIdx.x >> 6][k] = __builtin_readcyclecounter();
 #define PP_STAMP(k)                                                                                  \
     if (blockIdx.x == 0 && h >= PP_TRACE_H0 && h < PP_TRACE_H0 + 4 && lane == 0)                      \
         g_pp_trace[wave][h - PP_TRACE_H0][0][k] = __builtin_readcyclecounter();
 #else
 #define PP_STAMP(k)
+#define PP_PHASE(k)
 #endif
 
 __device__ __forceinline__ int pp_f(int row) { return (4 - ((row >> 2) & 3)) & 3; }
@@ -53,6 +58,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
     const int ugroup = uwave >> 2;
     const theia_rowmap_t& mp = p.map;
     const int tiles_n = (p.N + BN - 1) / BN;
+    PP_PHASE(0)
     const int tile = gt_xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const T* __restrict__ A = reinterpret_cast<const T*>(p.a);
@@ -61,14 +67,16 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
     const int st_chunk = tid & 3, st_row = tid >> 2;
     const int lchunk = st_chunk ^ pp_f(st_row);
     const int R = mp.rows_h * mp.rows_w;
+    const float rcp_R = 1.0f / (float)R, rcp_w = 1.0f / (float)mp.rows_w;
     int64_t a_base[NPA];
     int a_iy0[NPA], a_ix0[NPA];
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
         const int m = m0 + st_row + SRP * i;
         if (m < p.M) {
-            const int img = m / R, rem = m - img * R;
-            const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
+            int rem, rx;
+            const int img = gt_divmod(m, R, rcp_R, rem);
+            const int ry = gt_divmod(rem, mp.rows_w, rcp_w, rx);
             a_base[i] = (int64_t)img * mp.in_batch_stride + mp.in_offset;
             a_iy0[i] = ry * mp.in_sy;
             a_ix0[i] = rx * mp.in_sx;
@@ -125,6 +133,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
     const int hpt = mp.in_c / HKT;  // half-tiles per tap
+    PP_PHASE(1)
     int cur_tap = 0, next_tap_h = hpt;  // prefetch stream state: tap of half-tile hp, first half-tile of the next tap
     set_tap(0);
     // prologue: half-tiles 0..2 (clamped for very short K; the duplicates are never read)
@@ -141,6 +150,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
 #pragma unroll
         for (int q = 0; q < LPH; ++q) issue_piece(q, coff, sa, sa + BM * 64);
     }
+    PP_PHASE(2)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPH) : "memory");  // half-tile 0 landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -149,6 +159,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         asm volatile("" ::: "memory");
     }
 
+    PP_PHASE(3)
     const int frow = lane & 15, fg = lane >> 4;
     uint4 fb[FN];
     for (int h = 0; h < nh; ++h) {
@@ -204,12 +215,18 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the clamped tail prefetches before LDS is reused
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), as a builtin so that the compiler KNOWS no LDS-DMA is pending in the epilogue  // drain the clamped tail prefetches before LDS is reused
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    PP_PHASE(4)
     float* ep = reinterpret_cast<float*>(smem) + wave * (64 * (WN + 4));
     gt_epilogue<T, WM, WN>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
+    PP_PHASE(5)
+#ifdef PP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    PP_PHASE(6)
 }
 
 int theia_gemm_nt_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t stream) {

@@ -4,6 +4,10 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 gt_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float gt_f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int gt_u32x4;
+
+// 8 elements per lane that the epilogue's dead lanes (rows >= M, columns >= N) store to instead of branching around the store
+__device__ __attribute__((aligned(16))) static char g_gt_dump[64 * 32];
 
 template <typename T> struct GtMma;
 template <> struct GtMma<bf16_t> {
@@ -28,11 +32,28 @@ __device__ __forceinline__ int gt_xcd_remap(int bid, int nwg) {
     return start + idx;
 }
 
+// floor(m / d) and remainder for 0 <= m, d >= 1 with rcp = 1.0f / d hoisted by the caller: exact below 2^24 (the float
+// quotient is within one of the answer, two integer fix-ups), plain division above.  The row maps decode a GEMM row into
+// (image, y, x) with two of these per row; the hardware integer division they replace is ~40 VALU instructions each.
+__device__ __forceinline__ int gt_divmod(int m, int d, float rcp, int& rem) {
+    if (m >= (1 << 24)) {
+        const int q = m / d;
+        rem = m - q * d;
+        return q;
+    }
+    int q = (int)((float)m * rcp);
+    int r = m - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+    rem = r;
+    return q;
+}
+
 // fast exact-erf GELU pieces for the bf16 path: Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution);
 // the f32 (parity) path keeps libm erff.
 __device__ __forceinline__ float gt_erf_fast(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float r = 1.0f - poly * __expf(-ax * ax);
     return copysignf(r, x);
@@ -54,6 +75,9 @@ template <typename T> __device__ __forceinline__ float gt_gelu_grad(float x) {
 // with the WEIGHT fragment as the MFMA A operand (lane: m = j*16 + lane&15, n = i*16 + (lane>>4)*4 .. +4).
 // The tile goes through a wave-private LDS region (EPH rows at a time) and is re-read row-contiguously so that every
 // global access of the epilogue (bias, row table, residual, aux, output) is a 16-byte vector access.
+// The row passes are a ROLLED loop over groups of passes: fully unrolled the epilogue was ~70 KB of straight-line code
+// executed once per workgroup -- more than the 64 KB instruction cache, and the instruction fetch (not the stores) set its
+// duration (29-36k cycles per 256x256 tile; tools/pp_trace.hip).
 template <typename T, int WM, int WN>
 __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], float* ep /* wave-private LDS */,
                                             const theia_gemm_args_t& p, int m_wave0, int n_wave0, int lane) {
@@ -61,114 +85,152 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
     constexpr int EP_PITCH = WN + 4;
     constexpr int EPH = WM > 64 ? 64 : WM;
     constexpr int LPR = WN / 8, RPP = 64 / LPR;
+    constexpr int NPS = EPH / RPP;
     const theia_rowmap_t& mp = p.map;
     const int frow = lane & 15, fg = lane >> 4;
     const int R = mp.rows_h * mp.rows_w;
+    const float rcp_R = 1.0f / (float)R, rcp_w = 1.0f / (float)mp.rows_w;
     T* __restrict__ O = reinterpret_cast<T*>(p.out);
     const T* __restrict__ RES = reinterpret_cast<const T*>(p.resid);
     const T* __restrict__ AUXI = reinterpret_cast<const T*>(p.aux_in);
     T* __restrict__ AUXO = reinterpret_cast<T*>(p.aux_out);
-    const int col = (lane % LPR) * 8;
+    const int col = (lane % LPR) * 8, lrow = lane / LPR;
     const int n = n_wave0 + col;
+    const bool n_ok = n < p.N;
     float bias8[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bias8[j] = 0.f;
-    if (p.bias != nullptr && n < p.N) load8(p.bias + n, bias8);
+    if (p.bias != nullptr && n_ok) load8(p.bias + n, bias8);
+    const int act = p.act;
+    const bool want_aux = act == THEIA_ACT_MUL_DGELU || act == THEIA_ACT_MUL_DRELU;
+    const T* __restrict__ PRE = want_aux ? AUXI : RES;  // the row that is prefetched (bf16 path)
+    const bool pre_on = sizeof(T) == 2 && PRE != nullptr;
+    // output element offset of GEMM row m (column n), and whether this lane has anything to do there
+    auto row_offset = [&](int m, bool& live) -> int64_t {
+        live = (m < p.M) && n_ok;
+        const int mm = live ? m : 0;
+        int rem, rx;
+        const int img = gt_divmod(mm, R, rcp_R, rem);
+        const int ry = gt_divmod(rem, mp.rows_w, rcp_w, rx);
+        return (int64_t)img * mp.out_batch_stride + mp.out_offset +
+               (int64_t)((ry * mp.out_sy + mp.out_y0) * mp.out_w + rx * mp.out_sx + mp.out_x0) * p.ldo + (live ? n : 0);
+    };
+    auto unpack8 = [](const gt_u32x4& u, float (&f)[8]) {
+        const uint32_t w4[4] = {u[0], u[1], u[2], u[3]};
 #pragma unroll
-    for (int hf = 0; hf < WM / EPH; ++hf) {
-        // (1) issue every global read of this pass group first (residual / aux / row table): their latency then overlaps
-        //     the LDS round trip instead of being paid once per row pass
-        constexpr int NPS = EPH / RPP;
-        int64_t off[NPS];
-        bool live[NPS];
-        uint4 rpre[NPS];  // prefetched aux_in (ACT_MUL_*) or, otherwise, residual rows (bf16 path)
-        const bool want_aux = p.act == THEIA_ACT_MUL_DGELU || p.act == THEIA_ACT_MUL_DRELU;
-        const T* __restrict__ PRE = want_aux ? AUXI : RES;
-#pragma unroll
-        for (int ps = 0; ps < NPS; ++ps) {
-            const int row = ps * RPP + lane / LPR;
-            const int m = m_wave0 + hf * EPH + row;
-            live[ps] = (m < p.M) && (n < p.N);
-            const int mm = live[ps] ? m : 0;
-            const int img = mm / R, rem = mm - img * R;
-            const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
-            off[ps] = (int64_t)img * mp.out_batch_stride + mp.out_offset +
-                      (int64_t)((ry * mp.out_sy + mp.out_y0) * mp.out_w + rx * mp.out_sx + mp.out_x0) * p.ldo + (live[ps] ? n : 0);
-            rpre[ps] = make_uint4(0, 0, 0, 0);
-            if (sizeof(T) == 2 && PRE != nullptr && live[ps]) rpre[ps] = *reinterpret_cast<const uint4*>(PRE + off[ps]);
+        for (int j = 0; j < 4; ++j) {
+            f[2 * j] = __uint_as_float(w4[j] << 16);
+            f[2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u);
         }
-        // (2) accumulators -> wave-private LDS tile
+    };
+    // Passes are processed in groups of GP: the residual / aux_in rows of group g+1 are requested before group g's
+    // stores are issued.  vmcnt retires in order, so a load that follows a store waits for that store's acknowledgement
+    // (~1.7k cycles under load); one such wait per GROUP instead of one per pass.  Without residual / aux_in the loop has no
+    // vector-memory wait at all and the stores just stream out.
+    constexpr int GP = NPS < 4 ? NPS : 4;      // passes per group (unrolled: static registers for the prefetched rows)
+    constexpr int NG = WM / RPP / GP;          // groups per wave tile
+    constexpr int GPH = NPS / GP;              // groups per LDS half
+    static_assert(GP == 4 || GP == 2, "explicit waits below are written for 2 or 4 passes per group");
+    bool nlive[GP];
+    int64_t noff[GP];
+    gt_u32x4 npre[GP];
+    // The prefetch loads are inline asm, invisible to the compiler's waitcnt bookkeeping: it would otherwise wait with
+    // vmcnt(0) at their first use, i.e. also for every store issued since.  The explicit counted waits below (tied to the
+    // registers by "+v") are the only synchronisation of npre[].  Every pass issues its output store unconditionally
+    // (dead lanes store to a dump page), so at least GP vector-memory operations follow a group's prefetch.
+    auto fetch_group = [&](int g) {
 #pragma unroll
-        for (int i = 0; i < FN; ++i)
+        for (int q = 0; q < GP; ++q) {
+            noff[q] = row_offset(m_wave0 + lrow + (g * GP + q) * RPP, nlive[q]);
+            npre[q] = (gt_u32x4){0u, 0u, 0u, 0u};
+            if (pre_on)  // wave-uniform; dead lanes read row 0 (valid memory)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(npre[q]) : "v"(PRE + noff[q]) : "memory");
+        }
+    };
+    fetch_group(0);
+    if constexpr (GP == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(npre[0]), "+v"(npre[1]), "+v"(npre[2]), "+v"(npre[3])::"memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(npre[0]), "+v"(npre[1])::"memory");
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // the same vmcnt(0), visible to the compiler: the bias row has landed too
+    T* const dump = reinterpret_cast<T*>(g_gt_dump) + lane * 8;
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+        if (g % GPH == 0) {
+            // accumulators of the next EPH rows -> wave-private LDS tile (static register indices: one copy per half,
+            // selected by a wave-uniform branch)
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int jj = 0; jj < EPH / 16; ++jj) {
-                const int j = hf * (EPH / 16) + jj;
-                float* q = ep + (jj * 16 + frow) * EP_PITCH + i * 16 + fg * 4;
-                *reinterpret_cast<float4*>(q) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            for (int hf = 0; hf < WM / EPH; ++hf) {
+                if (g / GPH != hf) continue;
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < EPH / 16; ++jj) {
+                        const int j = hf * (EPH / 16) + jj;
+                        float* q = ep + (jj * 16 + frow) * EP_PITCH + i * 16 + fg * 4;
+                        *reinterpret_cast<float4*>(q) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    }
             }
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-        __builtin_amdgcn_wave_barrier();
-        // (3) row-contiguous passes
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+        }
+        bool live[GP];
+        int64_t off[GP];
+        gt_u32x4 pre[GP];
 #pragma unroll
-        for (int ps = 0; ps < NPS; ++ps) {
-            const int row = ps * RPP + lane / LPR;
-            if (!live[ps]) continue;
-            const int64_t o = off[ps];
+        for (int q = 0; q < GP; ++q) {
+            live[q] = nlive[q];
+            off[q] = noff[q];
+            pre[q] = npre[q];
+        }
+        if (g + 1 < NG) fetch_group(g + 1);
+#pragma unroll
+        for (int q = 0; q < GP; ++q) {  // straight-line per pass: dead lanes compute on row 0 and skip only the stores
+            const int64_t o = off[q];
+            const int row = ((g % GPH) * GP + q) * RPP + lrow;
             float v[8];
             load8(ep + row * EP_PITCH + col, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += bias8[j];
             if (p.rowtab != nullptr) {
-                const int m = m_wave0 + hf * EPH + row;
+                const int m = m_wave0 + lrow + (g * GP + q) * RPP;
                 float t8[8];
-                load8(p.rowtab + (int64_t)(m % p.rowtab_period) * p.N + n, t8);
+                load8(p.rowtab + (int64_t)(m % p.rowtab_period) * p.N + (n_ok ? n : 0), t8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += t8[j];
             }
             float a8[8];
             if (want_aux) {
-                if (sizeof(T) == 2) {
-                    const uint32_t w4[4] = {rpre[ps].x, rpre[ps].y, rpre[ps].z, rpre[ps].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        a8[2 * j] = __uint_as_float(w4[j] << 16);
-                        a8[2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u);
-                    }
-                } else {
-                    load8(AUXI + o, a8);
-                }
+                if (sizeof(T) == 2) unpack8(pre[q], a8);
+                else load8(AUXI + o, a8);
             }
-            if (p.act == THEIA_ACT_GELU) {
-                if (AUXO != nullptr) store8(AUXO + o, v);
+            if (act == THEIA_ACT_GELU) {
+                if (AUXO != nullptr) store8(live[q] ? AUXO + o : dump, v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = gt_gelu<T>(v[j]);
-            } else if (p.act == THEIA_ACT_RELU) {
+            } else if (act == THEIA_ACT_RELU) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-            } else if (p.act == THEIA_ACT_MUL_DGELU) {
+            } else if (act == THEIA_ACT_MUL_DGELU) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] *= gt_gelu_grad<T>(a8[j]);
-            } else if (p.act == THEIA_ACT_MUL_DRELU) {
+            } else if (act == THEIA_ACT_MUL_DRELU) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = a8[j] > 0.f ? v[j] : 0.f;
             }
             if (RES != nullptr) {
                 float r8[8];
-                if (sizeof(T) == 2 && !want_aux) {
-                    const uint32_t w4[4] = {rpre[ps].x, rpre[ps].y, rpre[ps].z, rpre[ps].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        r8[2 * j] = __uint_as_float(w4[j] << 16);
-                        r8[2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u);
-                    }
-                } else {
-                    load8(RES + o, r8);
-                }
+                if (sizeof(T) == 2 && !want_aux) unpack8(pre[q], r8);
+                else load8(RES + o, r8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += r8[j];
             }
-            store8(O + o, v);
+#ifdef GT_EP_NOSTORE
+            if (v[0] == 123456.f)
+#endif
+            store8(live[q] ? O + o : dump, v);
         }
-        __builtin_amdgcn_wave_barrier();  // the next pass reuses the wave's LDS region
+        // group g+1's rows have landed once at most the GP (or more) stores issued after them are outstanding
+        if constexpr (GP == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(npre[0]), "+v"(npre[1]), "+v"(npre[2]), "+v"(npre[3])::"memory");
+        else asm volatile("s_waitcnt vmcnt(2)" : "+v"(npre[0]), "+v"(npre[1])::"memory");
     }
 }
