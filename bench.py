@@ -190,7 +190,23 @@ def main():
             sq.join()
             torch.cuda.synchronize()
             sq.enabled = False
-            iso = [(t_, f_) for t_, f_, v_, _s in measure(NP) if v_ == dom_var]
+            if os.environ.get("THEIA_BENCH_GEMM_TABLE") and rank == 0:
+                ops.WGRAD_PROFILE = []
+            iso_recs = measure(NP)
+            iso = [(t_, f_) for t_, f_, v_, _s in iso_recs if v_ == dom_var]
+            if ops.WGRAD_PROFILE is not None:  # isolated per-shape tables (tuning aid)
+                wrecs, ops.WGRAD_PROFILE = ops.WGRAD_PROFILE, None
+                for label, rr in (("gemm_nt(isolated)", iso_recs),
+                                  ("gemm_wgrad(isolated)", [(e0.elapsed_time(e1) * 1e-3, fl, var, shp) for (e0, e1, fl, var, shp) in wrecs])):
+                    by = {}
+                    for t_, fl, var, shp in rr:
+                        d = by.setdefault((var,) + shp, [0, 0.0, 0.0])
+                        d[0] += 1
+                        d[1] += t_
+                        d[2] += fl
+                    log(f"{label}: total {sum(v[1] for v in by.values()) / NP * 1e3:.2f} ms/step, {sum(v[2] for v in by.values()) / sum(v[1] for v in by.values()) / 1e12:.1f} TF")
+                    for k, (cnt, tt, ff) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+                        log(f"{label} {k}: {cnt // NP:4d}/step  {tt / cnt * 1e6:8.1f} us  {ff / tt / 1e12:7.1f} TF  {tt / NP * 1e3:7.2f} ms/step")
             sq.enabled = True
             iso_tf = sum(f for _, f in iso) / sum(t for t, _ in iso) / 1e12
         else:

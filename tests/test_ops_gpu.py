@@ -171,7 +171,7 @@ def test_conv_family_fwd_dgrad_wgrad(dt, kind, C):
     rmap, mpi = plan.dgrad
     ops.gemm_nt(gyd, wdg, dx, b * mpi, C, 9 * C, rmap, 9 * C, C)
     assert relerr(dx.float(), xr.grad) < TOL[dt]
-    # weight gradient (all classes into one slab set, then one reduce)
+    # weight gradient: reduction over output pixels (all classes into one slab set, then one reduce) ...
     Mtot = b * OH * OH
     splits = ops.wgrad_splits(Mtot, C, 9 * C)
     slabs = torch.empty(splits * C * 9 * C, dtype=torch.float32, device=dev)
@@ -181,6 +181,11 @@ def test_conv_family_fwd_dgrad_wgrad(dt, kind, C):
     sn, ss, sc = plan.grad_strides
     ops.wgrad_reduce(slabs, splits, C, 9, C, gw, sn, ss, sc, accumulate=False)
     assert relerr(gw, Wr.grad) < TOL[dt]
+    # ... and the engine's entry point (stride-2 transposed convs reduce over input pixels instead), with accumulation
+    gw2 = torch.full((C, C, 3, 3), 0.5, dtype=torch.float32, device=dev)
+    ops.conv_wgrad(plan, gyd.view(b, -1), xd.view(b, -1), b, C, gw2, accumulate=True)
+    assert plan.wgrad_swapped == kind.startswith("convT_s2")
+    assert relerr(gw2 - 0.5, Wr.grad) < TOL[dt]
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

@@ -526,7 +526,7 @@ class StudentEngine:
             Ct = dp.shape[-1]
             E3 = s2 * s2 * C
             chw_need = N.lib().theia_layernorm_chw_workspace_bytes(b, E3) // 4
-            conv_slabs = max(ops.wgrad_splits(b * hw * hw, C, 9 * C) for hw in (16, s1, s2)) * 9 * C * C
+            conv_slabs = max(ops.conv_wgrad_splits(self._plan(k), b, C) for k in ("pad", "conv16", "up31", "up64")) * 9 * C * C
             lin_slabs = ops.wgrad_splits(b * s2 * s2, Ct, C) * Ct * C
             ws = self.ws(max(chw_need + 2 * E3 + 64, conv_slabs, lin_slabs,
                              N.lib().theia_colsum_workspace_bytes(b * s2 * s2, max(C, Ct)) // 4 + 64), dev)
@@ -556,12 +556,7 @@ class StudentEngine:
 
                 def task():
                     ops.colsum(dy2d, gb, accb, side.ws)
-                    splits = ops.wgrad_splits(mtot, C, 9 * C)
-                    slabs = side.ws[: splits * C * 9 * C]
-                    for rmap, mpi in plan.fwd:
-                        ops.gemm_wgrad(dy2d, x, slabs, b * mpi, C, C, 9, splits, rmap)
-                    sn, ss, sc = plan.grad_strides
-                    ops.wgrad_reduce(slabs, splits, C, 9, C, gw, sn, ss, sc, accw)
+                    ops.conv_wgrad(plan, dy2d, x, b, C, gw, accw, side.ws)
                 side.run(task, dy2d, x)
 
             def ln_bwd(dy, x, stats, idx, hw, relu_mask):

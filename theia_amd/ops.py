@@ -52,6 +52,7 @@ class ConvPlan:
     dgrad: (rowmap, M_per_image)
     pack_fwd / pack_dgrad: (d0, d1, d2, s0, s1, s2) arguments of theia_cast_permute3 producing W[n][slot][c]
     grad_strides: (sn, ss, sc) of theia_wgrad_reduce writing into the reference weight layout
+    wgrad_swapped: weight gradient as a reduction over INPUT pixels (conv_wgrad below) -- stride-2 transposed convs
     """
     fwd: List[Tuple[RowMap, int]]
     dgrad: Tuple[RowMap, int]
@@ -59,6 +60,7 @@ class ConvPlan:
     pack_dgrad: Tuple[int, int, int, int, int, int]
     grad_strides: Tuple[int, int, int]
     out_hw: int
+    wgrad_swapped: bool = False
 
 
 def plan_conv3x3(C: int, H: int, in_bs: Optional[int] = None, in_off: int = 0) -> ConvPlan:
@@ -93,7 +95,7 @@ def plan_convT3x3(C: int, IH: int, stride: int, padding: int, output_padding: in
     # d in[i,j] = sum_{ky,kx} d out[i*s - p + ky, j*s - p + kx] . W[ci, :, ky, kx]
     dg = rowmap([(ky - padding, kx - padding, ky * 3 + kx) for ky, kx in TAPS9], (IH, IH), (OH, OH), stride, C, obs, 0,
                 IH, 1, 0, 0, ibs, in_off)
-    return ConvPlan(fwd, (dg, IH * IH), (C, 9, C, 9, 1, C * 9), (C, 9, C, C * 9, 1, 9), (9, 1, C * 9), OH)
+    return ConvPlan(fwd, (dg, IH * IH), (C, 9, C, 9, 1, C * 9), (C, 9, C, C * 9, 1, 9), (9, 1, C * 9), OH, stride == 2)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -107,6 +109,7 @@ def _dt(t: torch.Tensor) -> int:
 
 # when set to a list, gemm_nt appends (start_event, end_event, algorithmic_flops, tile_variant, (M, N, K)) per launch
 GEMM_PROFILE: Optional[list] = None
+WGRAD_PROFILE: Optional[list] = None  # same for theia_gemm_wgrad launches
 
 
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int, K: int, rmap: RowMap, ldw: int, ldo: int,
@@ -150,6 +153,13 @@ def gemm_wgrad(dy: torch.Tensor, a: torch.Tensor, slabs: torch.Tensor, M: int, N
     g.dy, g.a, g.slabs = dy.data_ptr(), a.data_ptr(), slabs.data_ptr()
     g.M, g.N, g.ldo, g.kslots, g.splits = M, Nn, ldo, kslots, splits
     g.map = rmap
+    if WGRAD_PROFILE is not None:  # tuning aid (bench.py THEIA_BENCH_GEMM_TABLE): HIP events on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        N.check(N.lib().theia_gemm_wgrad(g, _dt(dy), N.stream_ptr()), "theia_gemm_wgrad")
+        e1.record()
+        WGRAD_PROFILE.append((e0, e1, 2.0 * M * Nn * kslots * rmap.in_c, f"s{splits}", (M, Nn, kslots * rmap.in_c)))
+        return
     N.check(N.lib().theia_gemm_wgrad(g, _dt(dy), N.stream_ptr()), "theia_gemm_wgrad")
 
 
@@ -161,6 +171,37 @@ def wgrad_reduce(slabs: torch.Tensor, splits: int, Nn: int, kslots: int, C: int,
                  accumulate: bool) -> None:
     N.check(N.lib().theia_wgrad_reduce(slabs.data_ptr(), splits, Nn, kslots, C, out.data_ptr(), sn, ss, sc, int(accumulate),
                                        N.stream_ptr()), "theia_wgrad_reduce")
+
+
+def conv_wgrad_splits(plan: ConvPlan, b: int, C: int) -> int:
+    """split count conv_wgrad will use (slab workspace = splits * 9 * C * C floats)."""
+    mpi = plan.dgrad[1] if plan.wgrad_swapped else sum(m for _r, m in plan.fwd)
+    return wgrad_splits(b * mpi, C, 9 * C)
+
+
+def conv_wgrad(plan: ConvPlan, dy: torch.Tensor, x: torch.Tensor, b: int, C: int, grad_w: torch.Tensor, accumulate: bool,
+               ws: Optional[torch.Tensor] = None) -> None:
+    """grad_w (reference layout, f32) (+)= weight gradient of one 3x3 (transposed) convolution.
+    dy: output gradient, flat NHWC [b, OH*OH*C]; x: the convolution's input (flat NHWC, possibly strided per the plan).
+
+    Stride-2 transposed convolutions reduce over INPUT pixels: dW[ci, co, tap] = sum_{b,i,j} x[b,i,j,ci] * dy[b, 2i-p+ky, 2j-p+kx, co]
+    -- theia_gemm_wgrad with the dgrad row map and the operands swapped (x is the dense operand, dy the gathered one).  Every
+    tap then has the same number of rows and one launch fills the chip; reducing over OUTPUT pixels needs one launch per
+    output-parity class with 1, 2, 2 and 4 live taps (27..108 workgroups each on 256 CUs)."""
+    splits = conv_wgrad_splits(plan, b, C)
+    need = splits * C * 9 * C
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=dy.device)
+    slabs = ws[:need]
+    if plan.wgrad_swapped:
+        rmap, mpi = plan.dgrad
+        gemm_wgrad(x, dy, slabs, b * mpi, C, C, 9, splits, rmap)
+        wgrad_reduce(slabs, splits, C, 9, C, grad_w, 9 * C, 1, 9, accumulate)  # slab[ci][tap][co] -> W[ci, co, ky, kx]
+    else:
+        for rmap, mpi in plan.fwd:
+            gemm_wgrad(dy, x, slabs, b * mpi, C, C, 9, splits, rmap)
+        sn, ss, sc = plan.grad_strides
+        wgrad_reduce(slabs, splits, C, 9, C, grad_w, sn, ss, sc, accumulate)
 
 
 def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, grad_w: torch.Tensor, accumulate: bool,
