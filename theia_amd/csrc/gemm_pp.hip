@@ -5,14 +5,16 @@
 // so whenever group 0 is in an M segment group 1 is in an R segment and vice versa: the matrix pipe of every SIMD is fed by
 // one wave while the SIMD's other wave fetches its next fragments (rocprofv3 on the lock-step kernels: 28 % MFMA busy, 42 %
 // of wave cycles parked in s_waitcnt/s_barrier).  Operands arrive by LDS-DMA (global_load_lds_dwordx4) into a 4-deep ring
-// of HALF k-tiles (32 bf16 / 16 f32 of k per row, 64-byte rows, source-side XOR swizzle as in gemm_ring.hip); two pieces of
-// half-tile h+3 are issued inside every M segment (behind MFMAs their issue cost is hidden) and only counted waits are used:
-//     end of R(h):  s_waitcnt vmcnt(4)  -> half-tile h+1 has landed (h+2 stays in flight, h+3 is issued in M(h))
-// One phase per half-tile: R(h) reads 4 B + 8 A fragments, M(h) issues 32 MFMAs (cycle trace, tools/pp_trace.hip: with 16
-// MFMAs per phase the R segment + two barriers, not the MFMAs, set the interval).
+// of HALF k-tiles (32 bf16 / 16 f32 of k per row, 64-byte rows, source-side XOR swizzle); the four pieces of half-tile h+3
+// are issued in R(h), right after the fragment reads (an LDS-DMA instruction costs ~60-100 issue cycles: between a group's
+// own MFMAs that is lost matrix-pipe time, in the R segment it overlaps the OTHER group's MFMAs; +5 % measured), and only
+// counted waits are used:
+//     end of R(h):  s_waitcnt vmcnt(8)  -> half-tile h+1 has landed (h+2 and the just-issued h+3 stay in flight)
+// One phase per half-tile: R(h) reads 4 B + 8 A fragments, M(h) issues 32 MFMAs (cycle trace, tools/pp_trace.hip: R is
+// ~720 cycles, M ~630, so the R segment -- 12 ds_read_b128 + 4 LDS-DMA issues -- sets the interval).
 //
 // Hazards (interval k = time between barrier k and k+1; group 0 runs segment k in interval k, group 1 segment k-1):
-//   WAR  ring slot (h+3)&3 = (h-1)&3 is refilled from M(h) on (interval >= 2h+1); its last readers are R(h-1) of group 0
+//   WAR  ring slot (h+3)&3 = (h-1)&3 is refilled from R(h) on (interval >= 2h); its last readers are R(h-1) of group 0
 //        (interval 2h-2) and of group 1 (interval 2h-1), both closed by s_waitcnt lgkmcnt(0) before their barrier.
 //   RAW  half-tile h+1 is first read in interval 2h+2 (group 0, R(h+1)); every wave has waited for its own pieces of it at
 //        the end of its R(h) (interval 2h / 2h+1), i.e. before barrier 2h+2.
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
     constexpr int NPA = BM / SRP, NPB = BN / SRP;
     constexpr int LPH = NPA + NPB;              // 4 LDS-DMA pieces per thread per half-tile
     constexpr int STAGE = (BM + BN) * 64;
-    static_assert(LPH == 4, "schedule below assumes 2 pieces per M segment");
+    static_assert(LPH == 4, "the counted waits assume 4 pieces per thread per half-tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         const char* sa = smem + (h & (NSTAGE - 1)) * STAGE;
         const char* sb = sa + BM * 64;
         {
-            // ---------------- R(h): 12 fragment reads
+            // ---------------- R(h): 12 fragment reads + the 4 LDS-DMA pieces of half-tile h+3
             PP_STAMP(0)
             uint4 fa[FM];
 #pragma unroll
@@ -188,21 +190,32 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
                 const int row = wm * WM + j * 16 + frow;
                 fa[j] = *reinterpret_cast<const uint4*>(sa + row * 64 + ((fg ^ pp_f(row)) << 4));
             }
+#ifndef PP_GLDS_IN_M  // default: the LDS-DMA pieces are issued in the R segment (their ~60-100 issue cycles each overlap the
+                      // OTHER group's MFMAs); -DPP_GLDS_IN_M puts them between this group's MFMAs (5% slower, 2 A/B runs)
+#pragma unroll
+            for (int q = 0; q < LPH; ++q) issue_piece(q, coff, na, nb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_STAMP(1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPH) : "memory");  // half-tile h+1 landed; h+2, h+3 may be in flight
+#else
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_STAMP(1)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPH) : "memory");  // half-tile h+1 landed; h+2 may still be in flight
+#endif
             __builtin_amdgcn_sched_barrier(0);
             PP_STAMP(2)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            // ---------------- M(h): 32 MFMAs + the 4 LDS-DMA pieces of half-tile h+3
+            // ---------------- M(h): 32 MFMAs
             PP_STAMP(3)
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
 #pragma unroll
                 for (int i = 0; i < FN; ++i) GtMma<T>::run(acc[i][j], fb[i], fa[j]);
+#ifdef PP_GLDS_IN_M
                 if ((j & 1) == 0) issue_piece(j >> 1, coff, na, nb);
+#endif
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);

@@ -32,6 +32,25 @@ def main():
     if a.csv:
         open(a.csv, "w").write("\n".join(lines) + "\n")
     print(f"total kernel time {total / 1e6:.2f} ms over {sum(r[1] for r in rows)} dispatches")
+    # GPU busy fraction (union of kernel intervals / span) over the last 60% of the trace (steady-state steps)
+    iv = c.execute("select start, end from kernels order by start").fetchall()
+    if iv:
+        t_lo = iv[0][0] + 0.4 * (iv[-1][1] - iv[0][0])
+        iv = [(s_, e_) for s_, e_ in iv if s_ >= t_lo]
+        busy, cur_s, cur_e, gaps = 0, iv[0][0], iv[0][1], []
+        for s_, e_ in iv[1:]:
+            if s_ > cur_e:
+                busy += cur_e - cur_s
+                gaps.append(s_ - cur_e)
+                cur_s, cur_e = s_, e_
+            else:
+                cur_e = max(cur_e, e_)
+        busy += cur_e - cur_s
+        span = iv[-1][1] - iv[0][0]
+        gaps.sort()
+        print(f"steady-state window {span / 1e6:.1f} ms: GPU busy {100.0 * busy / span:.1f}% ; {len(gaps)} idle gaps, "
+              f"total {sum(gaps) / 1e6:.2f} ms, median {gaps[len(gaps) // 2] / 1e3 if gaps else 0:.1f} us, "
+              f"{sum(1 for g_ in gaps if g_ > 20000)} gaps > 20 us totalling {sum(g_ for g_ in gaps if g_ > 20000) / 1e6:.2f} ms")
     for ln in lines[: a.top + 1]:
         print(ln)
 
