@@ -151,7 +151,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss_val = float(last.detach().float().cpu())
-    log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
+    # host time to enqueue ONE step into empty queues (untimed extra steps): the floor the launch path puts under a step
+    host_dt = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        step()
+        host_dt = min(host_dt, time.perf_counter() - th)
+    torch.cuda.synchronize()
+    log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step (host enqueue of one step: {host_dt * 1e3:.2f} ms)")
 
     roofline = None
     if not args.no_roofline:
@@ -233,6 +241,7 @@ def main():
                                    f"loss 0.9*cos+0.1*smoothL1, step = fwd+loss+bwd+grad all-reduce" +
                                    ("" if args.no_optimizer else "+fused AdamW"),
                        "global_batch": b * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
+            "host_enqueue_ms_per_step": round(host_dt * 1e3, 3),
             "model_flops_utilization": round(value / world * FLOPS_PER_IMAGE_FWD_BWD / MFMA_BF16_PEAK, 4)
             if args.backbone == BACKBONE else None,
         }

@@ -149,6 +149,25 @@ int theia_cast_transpose(const float* src, void* dst, int R, int C, int64_t ldd,
  * (Conv2d [co,ci,3,3] / ConvTranspose2d [ci,co,3,3] -> packed [n][slot][c]; LN affine [C,H,W] -> [HW,C]) */
 int theia_cast_permute3(const float* src, void* dst, int d0, int d1, int d2, int64_t s0, int64_t s1,
                         int64_t s2, int dtype, void* stream);
+/* One launch for a whole table of permuting casts (every operand of the step is rebuilt from the fp32 master weights after
+ * each optimizer update: ~250 casts / transposes / packs, launch-bound one by one).  Job j computes, for i < d0, j < d1,
+ * k < d2:   dst[i*t0 + j*t1 + k] = cast(src[i*s0 + j*s1 + k*s2])   (dst elements: `dtype`, or f32 when dst_f32 != 0).
+ * theia_cast_batch_plan fills the scheduling fields of a HOST table and returns the grid size; the table is then copied
+ * to the device once and reused while pointers and shapes stay the same. */
+typedef struct {
+    const float* src;
+    void* dst;
+    int32_t d0, d1, d2;
+    int32_t dst_f32;
+    int64_t s0, s1, s2; /* source element strides */
+    int64_t t0, t1;     /* destination element strides of i and j (k is contiguous) */
+    /* filled by theia_cast_batch_plan */
+    int64_t first_block;
+    int32_t tiles1, tiles2;
+    int32_t tile1, tile2;
+} theia_cast_job_t;
+int64_t theia_cast_batch_plan(theia_cast_job_t* jobs_host, int njobs);
+int theia_cast_batch(const theia_cast_job_t* jobs_device, int njobs, int64_t total_blocks, int dtype, void* stream);
 /* f32 -> f32 version writing with destination strides: dst[i*t0 + j*t1 + k*t2] (+)= src[(i*d1+j)*d2+k] */
 int theia_unpermute3_f32(const float* src, float* dst, int d0, int d1, int d2, int64_t t0, int64_t t1,
                          int64_t t2, int accumulate, void* stream);

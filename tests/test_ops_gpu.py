@@ -368,6 +368,50 @@ def test_token_select_modes_and_feature_norm(golden_dir):
     assert np.array_equal(y, g8["y"])  # two bf16 roundings reproduced bit-exactly
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_cast_batch_matches_single_casts(dt):
+    """theia_cast_batch (one launch for the whole operand table) == the individual cast / transpose / permute kernels,
+    bit for bit, including ragged shapes, strided destinations and f32 destinations."""
+    from theia_amd import ops
+    dev = _dev()
+    C = 48
+    w = h((100, 72), 41).to(dev)
+    wq = h((3, 40, 40), 42).to(dev)
+    cw = h((C, C, 3, 3), 43).to(dev)
+    g = h((C, 7, 7), 44).to(dev)
+    bias = h((77,), 45).to(dev)
+    cb = ops.CastBatch(dev, dt)
+    got, ref = {}, {}
+    got["w"], ref["w"] = torch.empty(100, 72, dtype=dt, device=dev), torch.empty(100, 72, dtype=dt, device=dev)
+    cb.add_cast(w, got["w"])
+    ops.cast(w, ref["w"])
+    got["wT"], ref["wT"] = torch.zeros(72, 100, dtype=dt, device=dev), torch.zeros(72, 100, dtype=dt, device=dev)
+    cb.add_transpose(w, got["wT"])
+    ops.cast_transpose(w, ref["wT"])
+    got["qT"], ref["qT"] = torch.zeros(40, 120, dtype=dt, device=dev), torch.zeros(40, 120, dtype=dt, device=dev)
+    for j in range(3):
+        cb.add_transpose(wq[j], got["qT"][:, j * 40:], ldd=120)
+        ops.cast_transpose(wq[j], ref["qT"][:, j * 40:], ldd=120)
+    for name, pack in (("cf", ops.plan_conv3x3(C, 16).pack_fwd), ("cd", ops.plan_conv3x3(C, 16).pack_dgrad),
+                       ("tf", ops.plan_convT3x3(C, 16, 2, 1, 0).pack_fwd), ("td", ops.plan_convT3x3(C, 16, 2, 1, 0).pack_dgrad)):
+        got[name], ref[name] = torch.empty(C, 9 * C, dtype=dt, device=dev), torch.empty(C, 9 * C, dtype=dt, device=dev)
+        cb.add(cw, got[name], *pack)
+        ops.cast_permute3(cw, ref[name], *pack)
+    got["g"], ref["g"] = torch.empty(49 * C, dtype=torch.float32, device=dev), torch.empty(49 * C, dtype=torch.float32, device=dev)
+    cb.add(g, got["g"], 1, 49, C, 0, 1, 49)
+    ops.cast_permute3(g, ref["g"], 49, 1, C, 1, 0, 49)
+    got["b"], ref["b"] = torch.empty(77, dtype=torch.float32, device=dev), torch.empty(77, dtype=torch.float32, device=dev)
+    cb.add_cast(bias, got["b"])
+    ops.cast(bias, ref["b"])
+    cb.run()
+    for k in got:
+        assert torch.equal(got[k], ref[k]), k
+    w.mul_(2.0)  # the table is reusable: same pointers, new values
+    cb.run()
+    ops.cast(w, ref["w"])
+    assert torch.equal(got["w"], ref["w"])
+
+
 def test_adamw_matches_torch():
     from theia_amd import ops
     dev = _dev()

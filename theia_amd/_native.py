@@ -47,6 +47,16 @@ class GemmArgs(C.Structure):
     ]
 
 
+class CastJob(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p), ("dst", C.c_void_p),
+        ("d0", C.c_int32), ("d1", C.c_int32), ("d2", C.c_int32), ("dst_f32", C.c_int32),
+        ("s0", C.c_int64), ("s1", C.c_int64), ("s2", C.c_int64),
+        ("t0", C.c_int64), ("t1", C.c_int64),
+        ("first_block", C.c_int64), ("tiles1", C.c_int32), ("tiles2", C.c_int32), ("tile1", C.c_int32), ("tile2", C.c_int32),
+    ]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [
         ("dy", C.c_void_p), ("a", C.c_void_p), ("slabs", C.c_void_p),
@@ -69,6 +79,8 @@ _SIGNATURES = {
     "theia_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "theia_colsum_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "theia_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "theia_cast_batch_plan": (C.c_int64, [C.c_void_p, C.c_int]),
+    "theia_cast_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "theia_cast_transpose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "theia_cast_permute3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64,
                                       C.c_int, C.c_void_p]),

@@ -33,8 +33,12 @@ __device__ unsigned long long g_pp_phase[2][8][7];
 #define PP_STAMP(k)                                                                                  \
     if (blockIdx.x == 0 && h >= PP_TRACE_H0 && h < PP_TRACE_H0 + 4 && lane == 0)                      \
         g_pp_trace[wave][h - PP_TRACE_H0][0][k] = __builtin_readcyclecounter();
+#define PP_STAMP2(k)                                                                                 \
+    if (blockIdx.x == 0 && h >= PP_TRACE_H0 && h < PP_TRACE_H0 + 4 && lane == 0)                      \
+        g_pp_trace[wave][h - PP_TRACE_H0][1][k] = __builtin_readcyclecounter();
 #else
 #define PP_STAMP(k)
+#define PP_STAMP2(k)
 #define PP_PHASE(k)
 #endif
 
@@ -190,10 +194,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
                 const int row = wm * WM + j * 16 + frow;
                 fa[j] = *reinterpret_cast<const uint4*>(sa + row * 64 + ((fg ^ pp_f(row)) << 4));
             }
+            PP_STAMP2(0)
 #ifndef PP_GLDS_IN_M  // default: the LDS-DMA pieces are issued in the R segment (their ~60-100 issue cycles each overlap the
                       // OTHER group's MFMAs); -DPP_GLDS_IN_M puts them between this group's MFMAs (5% slower, 2 A/B runs)
 #pragma unroll
             for (int q = 0; q < LPH; ++q) issue_piece(q, coff, na, nb);
+            PP_STAMP2(1)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_STAMP(1)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPH) : "memory");  // half-tile h+1 landed; h+2, h+3 may be in flight

@@ -99,6 +99,76 @@ extern "C" int theia_cast_permute3(const float* src, void* dst, int d0, int d1, 
     return THEIA_OK;
 }
 
+// Batched permuting cast: block -> (job, i, 32x32 or 16x64 tile of the (j, k) plane).  The tile goes through LDS so that the
+// source is read along whichever of j / k has the smaller source stride and the destination is written along k.
+template <typename T>
+__global__ __launch_bounds__(256) void cast_batch_kernel(const theia_cast_job_t* __restrict__ jobs, int njobs) {
+    __shared__ float tile[1024 + 64];
+    int lo = 0, hi = njobs - 1;  // last job with first_block <= blockIdx.x
+    const int64_t bid = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= bid) lo = mid; else hi = mid - 1;
+    }
+    const theia_cast_job_t jb = jobs[lo];
+    int64_t r = bid - jb.first_block;
+    const int tk = (int)(r % jb.tiles2);
+    r /= jb.tiles2;
+    const int tj = (int)(r % jb.tiles1), i = (int)(r / jb.tiles1);
+    const int T1 = jb.tile1, T2 = jb.tile2;          // T1 * T2 == 1024
+    const int j0 = tj * T1, k0 = tk * T2;
+    const float* __restrict__ src = jb.src + (int64_t)i * jb.s0;
+    const int P2 = T2 + 1;                             // LDS pitch of a j-row
+    if (jb.s1 < jb.s2) {                               // j is the fast source dimension
+        for (int e = threadIdx.x; e < 1024; e += 256) {
+            const int jj = e % T1, kk = e / T1;
+            const int j = j0 + jj, k = k0 + kk;
+            if (j < jb.d1 && k < jb.d2) tile[jj * P2 + kk] = src[j * jb.s1 + k * jb.s2];
+        }
+    } else {
+        for (int e = threadIdx.x; e < 1024; e += 256) {
+            const int kk = e % T2, jj = e / T2;
+            const int j = j0 + jj, k = k0 + kk;
+            if (j < jb.d1 && k < jb.d2) tile[jj * P2 + kk] = src[j * jb.s1 + k * jb.s2];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+        const int kk = e % T2, jj = e / T2;
+        const int j = j0 + jj, k = k0 + kk;
+        if (j < jb.d1 && k < jb.d2) {
+            const int64_t o = (int64_t)i * jb.t0 + (int64_t)j * jb.t1 + k;
+            const float v = tile[jj * P2 + kk];
+            if (jb.dst_f32) reinterpret_cast<float*>(jb.dst)[o] = v;
+            else Elem<T>::st(reinterpret_cast<T*>(jb.dst) + o, v);
+        }
+    }
+}
+extern "C" int64_t theia_cast_batch_plan(theia_cast_job_t* jobs, int njobs) {
+    if (jobs == nullptr || njobs <= 0) return 0;
+    int64_t blocks = 0;
+    for (int q = 0; q < njobs; ++q) {
+        theia_cast_job_t& jb = jobs[q];
+        if (jb.src == nullptr || jb.dst == nullptr || jb.d0 <= 0 || jb.d1 <= 0 || jb.d2 <= 0) return -1;
+        jb.tile1 = jb.d1 > 16 ? 32 : (jb.d1 > 4 ? 16 : (jb.d1 > 1 ? 4 : 1));
+        jb.tile2 = 1024 / jb.tile1;
+        jb.tiles1 = (jb.d1 + jb.tile1 - 1) / jb.tile1;
+        jb.tiles2 = (jb.d2 + jb.tile2 - 1) / jb.tile2;
+        jb.first_block = blocks;
+        blocks += (int64_t)jb.d0 * jb.tiles1 * jb.tiles2;
+    }
+    return blocks;
+}
+extern "C" int theia_cast_batch(const theia_cast_job_t* jobs_device, int njobs, int64_t total_blocks, int dtype, void* stream) {
+    THEIA_CHECK_ARG(jobs_device && njobs > 0 && total_blocks > 0 && total_blocks < (int64_t)1 << 31, "theia_cast_batch: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(cast_batch_kernel<bf16_t>, dim3((unsigned)total_blocks), dim3(256), 0, s, jobs_device, njobs),
+               hipLaunchKernelGGL(cast_batch_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, s, jobs_device, njobs),
+               "theia_cast_batch");
+    THEIA_CHECK_LAUNCH("theia_cast_batch");
+    return THEIA_OK;
+}
+
 __global__ void unpermute3_kernel(const float* __restrict__ src, float* __restrict__ dst, int d0, int d1, int d2,
                                   int64_t t0, int64_t t1, int64_t t2, int accumulate) {
     const int64_t n = (int64_t)d0 * d1 * d2;

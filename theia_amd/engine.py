@@ -86,7 +86,10 @@ class _SideQueue:
 
     ``run(fn, *tensors)`` enqueues ``fn`` behind everything issued so far on the current stream; the tensors it reads are
     pinned with ``record_stream`` so the caching allocator does not recycle them early; ``join()`` makes the current
-    stream wait for the queue.  With ``enabled=False`` everything runs inline (A/B switch THEIA_SIDE_STREAM=0)."""
+    stream wait for the queue; ``fence()`` only returns an event (for a consumer on a third stream, e.g. the gradient
+    all-reduce) and ``join_at_backward_end()`` defers the join to the end of the running autograd backward pass, so the
+    main stream never idles on the queue in the middle of backward.  With ``enabled=False`` everything runs inline (A/B
+    switch THEIA_SIDE_STREAM=0)."""
 
     def __init__(self, device, enabled: bool = True):
         self.device = device
@@ -94,6 +97,7 @@ class _SideQueue:
         self.stream = torch.cuda.Stream(device=device) if enabled else None
         self.ws: Optional[torch.Tensor] = None
         self._dirty = False
+        self._cb_queued = False
 
     def ensure_ws(self, nfloats: int) -> None:
         if self.ws is None or self.ws.numel() < nfloats:
@@ -119,6 +123,29 @@ class _SideQueue:
             ev.record(self.stream)
             torch.cuda.current_stream(self.device).wait_event(ev)
             self._dirty = False
+
+    def fence(self) -> Optional["torch.cuda.Event"]:
+        """Event marking everything queued so far (None when there is nothing to wait for)."""
+        if not (self.enabled and self._dirty):
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
+    def join_at_backward_end(self) -> None:
+        """join() once, when the autograd backward pass that is running finishes (queue_callback: the mechanism DDP uses
+        for its final synchronisation); outside a backward pass, join now."""
+        if not (self.enabled and self._dirty) or self._cb_queued:
+            return
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(self._backward_end)
+            self._cb_queued = True
+        except RuntimeError:  # "Final callbacks can only be installed during backward pass."
+            self.join()
+
+    def _backward_end(self) -> None:
+        self._cb_queued = False
+        self.join()
 
 
 class GradBucket:
@@ -166,12 +193,16 @@ class StudentEngine:
         self.D, self.heads, self.F = vit.hidden_size, vit.num_heads, vit.intermediate_size
         self._opcache: Dict[str, torch.Tensor] = {}
         self._opkey = None
+        self._op_ptr_key = None
+        self._opbatch = None
         self._ws: Optional[torch.Tensor] = None
         self._luts: Dict[Tuple[bool, bool], torch.Tensor] = {}
         self._plans: Dict[str, Any] = {}
         self.buckets: List[GradBucket] = []
         self._bucket_of: Dict[int, Tuple[GradBucket, int]] = {}
-        self.bucket_ready_hook: Optional[Callable[[GradBucket], None]] = None
+        # called as hook(bucket, side_event) when a bucket's gradients are complete once the CURRENT stream and side_event
+        # (a torch.cuda.Event on the weight-gradient side stream, or None) have been reached
+        self.bucket_ready_hook: Optional[Callable[[GradBucket, Optional[torch.cuda.Event]], None]] = None
         self._build_buckets()
 
     # ------------------------------------------------------------------ parameters & buckets
@@ -220,9 +251,11 @@ class StudentEngine:
             p.grad = v
         return v, True
 
-    def _bucket_done(self, b: GradBucket) -> None:
+    def _bucket_done(self, b: GradBucket, side: Optional["_SideQueue"] = None) -> None:
         if self.bucket_ready_hook is not None:
-            self.bucket_ready_hook(b)
+            self.bucket_ready_hook(b, side.fence() if side is not None else None)
+        if side is not None:
+            side.join_at_backward_end()
 
     # ------------------------------------------------------------------ small helpers
     def _side_queue(self, device, nfloats: int) -> "_SideQueue":
@@ -266,57 +299,66 @@ class StudentEngine:
 
     # ------------------------------------------------------------------ operand cache
     def _operands(self, device) -> Dict[str, torch.Tensor]:
+        """bf16 / f32 GEMM operands (plain, transposed and packed copies of the fp32 master weights), rebuilt by ONE batched
+        cast launch whenever a parameter changed (i.e. after every optimizer step)."""
         params = self.all_params()
-        key = (device, self.dtype, PARAM_EPOCH[0]) + tuple((p._version, p.data_ptr()) for p in params)
-        if key == self._opkey:
+        ptr_key = (device, self.dtype) + tuple((p.data_ptr(), tuple(p.shape)) for p in params)
+        key = (PARAM_EPOCH[0],) + tuple(p._version for p in params)
+        if ptr_key == self._op_ptr_key and key == self._opkey:
             return self._opcache
+        if ptr_key != self._op_ptr_key:
+            self._opcache, self._opbatch = self._build_operand_table(device)
+            self._op_ptr_key = ptr_key
+        self._opbatch.run()
+        self._opkey = key
+        return self._opcache
+
+    def _build_operand_table(self, device):
         T, D, F = self.dtype, self.D, self.F
         oc: Dict[str, torch.Tensor] = {}
+        cb = ops.CastBatch(device, T)
 
         def new(name, *shape, dtype=T):
-            t = self._opcache.get(name)
-            if t is None or t.shape != tuple(shape) or t.dtype != dtype or t.device != device:
-                t = torch.empty(*shape, dtype=dtype, device=device)
+            t = torch.empty(*shape, dtype=dtype, device=device)
             oc[name] = t
             return t
 
         vit = self.rvfm.backbone.model
-        ops.cast(vit.embeddings.patch_embeddings.projection.weight, new("patch.w", D, 768))
+        cb.add_cast(vit.embeddings.patch_embeddings.projection.weight.view(D, 768), new("patch.w", D, 768))
         for i, L in enumerate(vit.layers):
             a = L.attention
             wqkv = new(f"l{i}.wqkv", 3 * D, D)
             wqkvT = new(f"l{i}.wqkvT", D, 3 * D)
             bqkv = new(f"l{i}.bqkv", 3 * D, dtype=torch.float32)
             for j, prj in enumerate((a.q_proj, a.k_proj, a.v_proj)):
-                ops.cast(prj.weight, wqkv[j * D:(j + 1) * D])
-                ops.cast_transpose(prj.weight, wqkvT[:, j * D:], ldd=3 * D)
-                ops.cast(prj.bias, bqkv[j * D:(j + 1) * D])
-            ops.cast(a.o_proj.weight, new(f"l{i}.wo", D, D))
-            ops.cast_transpose(a.o_proj.weight, new(f"l{i}.woT", D, D))
-            ops.cast(L.mlp.fc1.weight, new(f"l{i}.w1", F, D))
-            ops.cast_transpose(L.mlp.fc1.weight, new(f"l{i}.w1T", D, F))
-            ops.cast(L.mlp.fc2.weight, new(f"l{i}.w2", D, F))
-            ops.cast_transpose(L.mlp.fc2.weight, new(f"l{i}.w2T", F, D))
+                cb.add_cast(prj.weight, wqkv[j * D:(j + 1) * D])
+                cb.add_transpose(prj.weight, wqkvT[:, j * D:], ldd=3 * D)
+                cb.add_cast(prj.bias, bqkv[j * D:(j + 1) * D])
+            cb.add_cast(a.o_proj.weight, new(f"l{i}.wo", D, D))
+            cb.add_transpose(a.o_proj.weight, new(f"l{i}.woT", D, D))
+            cb.add_cast(L.mlp.fc1.weight, new(f"l{i}.w1", F, D))
+            cb.add_transpose(L.mlp.fc1.weight, new(f"l{i}.w1T", D, F))
+            cb.add_cast(L.mlp.fc2.weight, new(f"l{i}.w2", D, F))
+            cb.add_transpose(L.mlp.fc2.weight, new(f"l{i}.w2T", F, D))
         C = D
         for t, hm in self.head_modules():
             pf = f"h:{t}."
             pad_plan = self._plan("pad")
-            ops.cast_permute3(hm.pad["1"].weight, new(pf + "pad.wf", C, 9 * C), *pad_plan.pack_fwd)
-            ops.cast_permute3(hm.pad["1"].weight, new(pf + "pad.wd", C, 9 * C), *pad_plan.pack_dgrad)
+            cb.add(hm.pad["1"].weight, new(pf + "pad.wf", C, 9 * C), *pad_plan.pack_fwd)
+            cb.add(hm.pad["1"].weight, new(pf + "pad.wd", C, 9 * C), *pad_plan.pack_dgrad)
             for idx, pk in (("1", "up31"), ("4", "up64")) if hm.kind == "up64" else (("1", "conv16"), ("4", "conv16")):
                 pl = self._plan(pk)
-                ops.cast_permute3(hm.adapter[idx].weight, new(pf + f"c{idx}.wf", C, 9 * C), *pl.pack_fwd)
-                ops.cast_permute3(hm.adapter[idx].weight, new(pf + f"c{idx}.wd", C, 9 * C), *pl.pack_dgrad)
+                cb.add(hm.adapter[idx].weight, new(pf + f"c{idx}.wf", C, 9 * C), *pl.pack_fwd)
+                cb.add(hm.adapter[idx].weight, new(pf + f"c{idx}.wd", C, 9 * C), *pl.pack_dgrad)
             for idx, hw in zip(("0", "3", "6"), hm.sizes):
                 HW = hw * hw
-                ops.cast_permute3(hm.adapter[idx].weight, new(pf + f"ln{idx}.g", HW * C, dtype=torch.float32), HW, 1, C, 1, 0, HW)
-                ops.cast_permute3(hm.adapter[idx].bias, new(pf + f"ln{idx}.b", HW * C, dtype=torch.float32), HW, 1, C, 1, 0, HW)
+                # LN affine [C, H, W] -> [HW, C] (f32): a 2-D transpose, j = pixel (unit source stride), k = channel
+                cb.add(hm.adapter[idx].weight, new(pf + f"ln{idx}.g", HW * C, dtype=torch.float32), 1, HW, C, 0, 1, HW)
+                cb.add(hm.adapter[idx].bias, new(pf + f"ln{idx}.b", HW * C, dtype=torch.float32), 1, HW, C, 0, 1, HW)
             Ct = hm.adapter["8"].weight.shape[0]
-            ops.cast(hm.adapter["8"].weight, new(pf + "w8", Ct, C))
-            ops.cast_transpose(hm.adapter["8"].weight, new(pf + "w8T", C, Ct))
-        self._opcache = oc
-        self._opkey = key
-        return oc
+            cb.add_cast(hm.adapter["8"].weight, new(pf + "w8", Ct, C))
+            cb.add_transpose(hm.adapter["8"].weight, new(pf + "w8T", C, Ct))
+        return oc, cb
 
     # ================================================================== backbone
     def backbone(self, x: Any, do_rescale: bool = True, do_normalize: bool = True) -> torch.Tensor:
@@ -430,8 +472,7 @@ class StudentEngine:
             dh = ops.layernorm_bwd(da, h, L.layernorm_before.weight, mean1, rstd1, dh1, g1w, g1b, acc, ws)
             del da, dh1
             if i in group_lo:
-                side.join()
-                self._bucket_done(group_lo[i])
+                self._bucket_done(group_lo[i], side)
         # embeddings: h0[b, 0] = cls + pos[0];  h0[b, 1+p] = patches @ Wp^T + bias + pos[1+p]
         emb = vit.embeddings
         gpos, acc = self._grad(emb.position_embeddings)
@@ -450,8 +491,7 @@ class StudentEngine:
         slabs = ws[: splits * D * 768]
         ops.gemm_wgrad(dh, saved["patches"], slabs, Mp, D, D, 1, splits, rmap)
         ops.wgrad_reduce(slabs, splits, D, 1, 768, gpw, 768, 0, 1, acc)
-        side.join()
-        self._bucket_done(vit_buckets[3])
+        self._bucket_done(vit_buckets[3], side)
 
     # ================================================================== translator heads
     def translator(self, z: torch.Tensor, names: List[str]) -> Dict[str, torch.Tensor]:
@@ -596,8 +636,7 @@ class StudentEngine:
             conv_dgrad(du1, oc[pf + "pad.wd"], self._plan("pad"), dz, resid=dz)
             del du1
             if train:
-                side.join()
-                self._bucket_done(bucket)
+                self._bucket_done(bucket, side)
         return dz
 
     # ================================================================== loss

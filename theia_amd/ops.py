@@ -241,6 +241,56 @@ def cast_permute3(src: torch.Tensor, dst: torch.Tensor, d0: int, d1: int, d2: in
             "theia_cast_permute3")
 
 
+class CastBatch:
+    """A table of permuting casts executed by ONE launch (theia_cast_batch): the per-step rebuild of every GEMM operand
+    from the fp32 master weights.  add_*() while building, then run() any number of times; the table is bound to the data
+    pointers it was built with."""
+
+    def __init__(self, device, dtype: torch.dtype):
+        self.device, self.dtype = device, dtype
+        self.jobs: List[N.CastJob] = []
+        self._dev: Optional[torch.Tensor] = None
+        self._blocks = 0
+        self._keep: List[torch.Tensor] = []
+
+    def add(self, src: torch.Tensor, dst: torch.Tensor, d0: int, d1: int, d2: int, s0: int, s1: int, s2: int,
+            t0: Optional[int] = None, t1: Optional[int] = None) -> None:
+        """dst[i*t0 + j*t1 + k] = cast(src[i*s0 + j*s1 + k*s2]); default t: contiguous [d0, d1, d2]."""
+        assert src.dtype == torch.float32 and dst.dtype in (self.dtype, torch.float32) and self._dev is None
+        j = N.CastJob()
+        j.src, j.dst = src.data_ptr(), dst.data_ptr()
+        j.d0, j.d1, j.d2, j.dst_f32 = d0, d1, d2, int(dst.dtype == torch.float32 and self.dtype != torch.float32)
+        j.s0, j.s1, j.s2 = s0, s1, s2
+        j.t0, j.t1 = (d1 * d2 if t0 is None else t0), (d2 if t1 is None else t1)
+        self.jobs.append(j)
+        self._keep += [src, dst]
+
+    def add_cast(self, src: torch.Tensor, dst: torch.Tensor) -> None:
+        """element-wise cast of a contiguous tensor (2-D view [rows, cols] when it has one)."""
+        cols = src.shape[-1] if src.dim() >= 2 else src.numel()
+        rows = src.numel() // cols
+        self.add(src, dst, 1, rows, cols, 0, cols, 1)
+
+    def add_transpose(self, src: torch.Tensor, dst: torch.Tensor, ldd: Optional[int] = None) -> None:
+        """dst[c*ldd + r] = src[r, c] for a contiguous [R, C] matrix."""
+        R, Cc = src.shape
+        self.add(src, dst, 1, Cc, R, 0, 1, Cc, 0, ldd or R)
+
+    def run(self) -> None:
+        if not self.jobs:
+            return
+        if self._dev is None:
+            import ctypes
+            arr = (N.CastJob * len(self.jobs))(*self.jobs)
+            self._blocks = N.lib().theia_cast_batch_plan(ctypes.addressof(arr), len(self.jobs))
+            if self._blocks <= 0:
+                raise N.TheiaNativeError("theia_cast_batch_plan: bad job table")
+            raw = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr))), dtype=torch.uint8)
+            self._dev = raw.to(self.device)
+        N.check(N.lib().theia_cast_batch(self._dev.data_ptr(), len(self.jobs), self._blocks, N.dtype_code(self.dtype), N.stream_ptr()),
+                "theia_cast_batch")
+
+
 def unpermute3(src: torch.Tensor, dst: torch.Tensor, d0: int, d1: int, d2: int, t0: int, t1: int, t2: int,
                accumulate: bool) -> None:
     N.check(N.lib().theia_unpermute3_f32(src.data_ptr(), dst.data_ptr(), d0, d1, d2, t0, t1, t2, int(accumulate),

@@ -27,7 +27,9 @@ class GradBucketReducer:
         self._pending: List = []
         self._side: Optional[torch.cuda.Stream] = None
 
-    def bucket_ready(self, flat: torch.Tensor) -> None:
+    def bucket_ready(self, flat: torch.Tensor, also_after: Optional["torch.cuda.Event"] = None) -> None:
+        """flat is complete once the current stream -- and ``also_after`` (an event on another producer stream: the
+        engine's weight-gradient queue) -- have been reached; the all-reduce waits for both on its own stream."""
         if self.world == 1:
             return
         if flat.is_cuda:
@@ -37,6 +39,8 @@ class GradBucketReducer:
             ev.record(torch.cuda.current_stream(flat.device))
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ev)
+                if also_after is not None:
+                    self._side.wait_event(also_after)
                 work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
             self._pending.append((work, flat, False))
         else:  # gloo has no AVG: sum, then scale on completion
@@ -74,12 +78,12 @@ class TheiaDataParallel(torch.nn.Module):
         if self.reducer.world > 1:
             module.engine.bucket_ready_hook = self._on_bucket
 
-    def _on_bucket(self, bucket) -> None:
+    def _on_bucket(self, bucket, side_event=None) -> None:
         if not self._callback_queued:
             # runs once when the current backward pass has finished (same mechanism DDP uses)
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
             self._callback_queued = True
-        self.reducer.bucket_ready(bucket.flat)
+        self.reducer.bucket_ready(bucket.flat, side_event)
 
     def _finalize(self) -> None:
         self.reducer.finish()

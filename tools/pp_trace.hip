@@ -33,13 +33,16 @@ int main(int argc, char** argv) {
     unsigned long long t[8][4][2][5];
     hipMemcpyFromSymbol(t, HIP_SYMBOL(g_pp_trace), sizeof(t));
     const unsigned long long t0 = t[0][0][0][0];
+    // per half-tile: R start, fragment reads issued, LDS-DMA issued, fragments landed, own pieces landed, M start, M end
     for (int wv = 0; wv < 8; ++wv) {
         printf("wave %d:", wv);
-        for (int h = 0; h < 4; ++h)
-            for (int s = 0; s < 2; ++s) {
-                printf(" |");
-                for (int k = 0; k < 5; ++k) printf(" %5lld", (long long)(t[wv][h][s][k] - t0));
-            }
+        for (int h = 0; h < 4; ++h) {
+            const long long v[7] = {(long long)(t[wv][h][0][0] - t0), (long long)(t[wv][h][1][0] - t0), (long long)(t[wv][h][1][1] - t0),
+                                    (long long)(t[wv][h][0][1] - t0), (long long)(t[wv][h][0][2] - t0), (long long)(t[wv][h][0][3] - t0),
+                                    (long long)(t[wv][h][0][4] - t0)};
+            printf(" |");
+            for (int k = 0; k < 7; ++k) printf(" %5lld", v[k]);
+        }
         printf("\n");
     }
     unsigned long long ph[2][8][7];
