@@ -295,7 +295,9 @@ extern "C" int theia_gemm_nt(const theia_gemm_args_t* a, int dtype, void* stream
         const char* e = getenv("THEIA_GEMM_KERNEL");
         use_pp = (e != nullptr && strcmp(e, "std") == 0) ? 0 : 1;
     }
-    if (use_pp && tile == 256256 && a->K % (dtype == THEIA_BF16 ? 32 : 16) == 0) return theia_gemm_nt_pp_launch(a, dtype, s);
+    if (use_pp && tile == 256256 && a->K % (dtype == THEIA_BF16 ? 32 : 16) == 0 &&
+        (int64_t)a->map.in_c * (dtype == THEIA_BF16 ? 2 : 4) <= 16384)  // one tap's row fits the ping-pong kernel's zero page
+        return theia_gemm_nt_pp_launch(a, dtype, s);
     if (dtype == THEIA_BF16) {
         if (tile == 256256) return launch_gemm_nt<bf16_t, 256, 256, 2, 4>(a, s);
         return tile == 128064 ? launch_gemm_nt<bf16_t, 128, 64, 2, 2>(a, s) : launch_gemm_nt<bf16_t, 128, 128, 2, 2>(a, s);

@@ -20,7 +20,9 @@
 //        the end of its R(h) (interval 2h / 2h+1), i.e. before barrier 2h+2.
 #include "gemm_tile.h"
 
-__device__ uint4 g_pp_zero_page[16];
+// zeros read by out-of-range rows / taps: such a lane's source pointer is the page start and advances with the k offset
+// inside a tap like every other lane's, so the page covers one tap's row (in_c elements <= 16 KiB, checked by the dispatch)
+__device__ uint4 g_pp_zero_page[1024 + 1];
 
 // Optional cycle trace (tools/pp_trace.hip builds this file with -DPP_TRACE): s_memtime stamps of block 0 at the segment
 // boundaries of iterations PP_TRACE_H0 .. PP_TRACE_H0+3, one row per wave.  Compiled out of the library.
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
     const uint64_t zp = reinterpret_cast<uint64_t>(g_pp_zero_page);
     // Per-tap source pointers of this thread's LDS-DMA pieces (recomputed only when the prefetch stream enters a new tap, a
     // wave-uniform event): inside the M segments a piece costs one masked 64-bit add + the LDS-DMA issue.
-    uint64_t src_ptr[LPH], src_msk[LPH];
+    uint64_t src_ptr[LPH];
     auto set_tap = [&](int tap) {
         const int dy = mp.dy[tap], dx = mp.dx[tap];
         const int64_t wcol = (int64_t)mp.wslot[tap] * mp.in_c + lchunk * EPC;
@@ -122,18 +124,16 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
             const uint64_t pa = reinterpret_cast<uint64_t>(A + a_base[q] + (int64_t)(iy * mp.in_w + ix) * mp.in_c + lchunk * EPC);
             const uint64_t msk = 0ull - (uint64_t)ok;
             src_ptr[q] = (pa & msk) | (zp & ~msk);
-            src_msk[q] = msk;
         }
 #pragma unroll
         for (int i = 0; i < NPB; ++i) {
             const uint64_t pw = reinterpret_cast<uint64_t>(W + w_base[i] + wcol);
             const uint64_t msk = 0ull - (uint64_t)w_ok[i];
             src_ptr[NPA + i] = (pw & msk) | (zp & ~msk);
-            src_msk[NPA + i] = msk;
         }
     };
     auto issue_piece = [&](int q, uint64_t coff, char* sa, char* sb) {
-        const uint64_t src = src_ptr[q] + (coff & src_msk[q]);
+        const uint64_t src = src_ptr[q] + coff;
         char* dst = q < NPA ? sa + q * (SRP * 64) : sb + (q - NPA) * (SRP * 64);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);

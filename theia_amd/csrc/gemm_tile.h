@@ -78,7 +78,7 @@ template <typename T> __device__ __forceinline__ float gt_gelu_grad(float x) {
 // The row passes are a ROLLED loop over groups of passes: fully unrolled the epilogue was ~70 KB of straight-line code
 // executed once per workgroup -- more than the 64 KB instruction cache, and the instruction fetch (not the stores) set its
 // duration (29-36k cycles per 256x256 tile; tools/pp_trace.hip).
-template <typename T, int WM, int WN>
+template <typename T, int WM, int WN, int GPMAX = 4>
 __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], float* ep /* wave-private LDS */,
                                             const theia_gemm_args_t& p, int m_wave0, int n_wave0, int lane) {
     constexpr int FM = WM / 16, FN = WN / 16;
@@ -127,7 +127,7 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
     // stores are issued.  vmcnt retires in order, so a load that follows a store waits for that store's acknowledgement
     // (~1.7k cycles under load); one such wait per GROUP instead of one per pass.  Without residual / aux_in the loop has no
     // vector-memory wait at all and the stores just stream out.
-    constexpr int GP = NPS < 4 ? NPS : 4;      // passes per group (unrolled: static registers for the prefetched rows)
+    constexpr int GP = NPS < GPMAX ? NPS : GPMAX;      // passes per group (unrolled: static registers for the prefetched rows)
     constexpr int NG = WM / RPP / GP;          // groups per wave tile
     constexpr int GPH = NPS / GP;              // groups per LDS half
     static_assert(GP == 4 || GP == 2, "explicit waits below are written for 2 or 4 passes per group");
