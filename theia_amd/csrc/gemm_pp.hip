@@ -24,6 +24,11 @@
 // inside a tap like every other lane's, so the page covers one tap's row (in_c elements <= 16 KiB, checked by the dispatch)
 __device__ uint4 g_pp_zero_page[1024 + 1];
 
+// Ablation switches for tools/pp_trace.hip (timing only, results are wrong): -DPP_EXP_NOMFMA / -DPP_EXP_NODMA / -DPP_EXP_NOLDS
+// drop the MFMAs / the LDS-DMA operand stream / the fragment reads from the main loop.  One round of 255 tiles with
+// K = 6912 (255 CUs busy): everything 220 us, LDS-DMA only 172 us, MFMA only 121 us, and LDS-DMA only on 24 CUs 120 us --
+// the L2 -> LDS operand stream (32 KiB per CU per half-tile, ~10 TB/s over the chip at most, 64- or 128-byte rows alike),
+// not the matrix pipe, bounds this kernel at full occupancy.
 // Optional cycle trace (tools/pp_trace.hip builds this file with -DPP_TRACE): s_memtime stamps of block 0 at the segment
 // boundaries of iterations PP_TRACE_H0 .. PP_TRACE_H0+3, one row per wave.  Compiled out of the library.
 #ifdef PP_TRACE
@@ -168,6 +173,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
     PP_PHASE(3)
     const int frow = lane & 15, fg = lane >> 4;
     uint4 fb[FN];
+#ifdef PP_EXP_NOLDS
+    const int h_nolds = p.K < 0 ? 1 : -1;  // never true, but unknown to the compiler
+    uint4 fa[FM];
+    for (int j = 0; j < FM; ++j) fa[j] = make_uint4(tid, tid, tid, tid);
+    for (int i = 0; i < FN; ++i) fb[i] = make_uint4(tid, tid, tid, tid);
+#endif
     for (int h = 0; h < nh; ++h) {
         const int hp = min(h + NSTAGE - 1, nh - 1);  // half-tile prefetched during this iteration (clamped at the tail)
         if (hp >= next_tap_h) {                       // wave-uniform, once per in_c/HKT iterations
@@ -183,22 +194,32 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         {
             // ---------------- R(h): 12 fragment reads + the 4 LDS-DMA pieces of half-tile h+3
             PP_STAMP(0)
+#ifndef PP_EXP_NOLDS
             uint4 fa[FM];
+#endif
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
                 const int row = wn * WN + i * 16 + frow;
+#ifdef PP_EXP_NOLDS
+                if (h == h_nolds)
+#endif
                 fb[i] = *reinterpret_cast<const uint4*>(sb + row * 64 + ((fg ^ pp_f(row)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
                 const int row = wm * WM + j * 16 + frow;
+#ifdef PP_EXP_NOLDS
+                if (h == h_nolds)
+#endif
                 fa[j] = *reinterpret_cast<const uint4*>(sa + row * 64 + ((fg ^ pp_f(row)) << 4));
             }
             PP_STAMP2(0)
 #ifndef PP_GLDS_IN_M  // default: the LDS-DMA pieces are issued in the R segment (their ~60-100 issue cycles each overlap the
                       // OTHER group's MFMAs); -DPP_GLDS_IN_M puts them between this group's MFMAs (5% slower, 2 A/B runs)
+#ifndef PP_EXP_NODMA
 #pragma unroll
             for (int q = 0; q < LPH; ++q) issue_piece(q, coff, na, nb);
+#endif
             PP_STAMP2(1)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_STAMP(1)
@@ -218,7 +239,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
 #pragma unroll
+#ifdef PP_EXP_NOMFMA
+                for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(fb[i].x), "v"(fb[i].y), "v"(fb[i].z), "v"(fb[i].w), "v"(fa[j].x), "v"(fa[j].y), "v"(fa[j].z), "v"(fa[j].w));
+#else
                 for (int i = 0; i < FN; ++i) GtMma<T>::run(acc[i][j], fb[i], fa[j]);
+#endif
 #ifdef PP_GLDS_IN_M
                 if ((j & 1) == 0) issue_piece(j >> 1, coff, na, nb);
 #endif

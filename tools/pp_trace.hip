@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
     if (resid) g.resid = res;
     for (int it = 0; it < 3; ++it) theia_gemm_nt_pp_launch(&g, THEIA_BF16, 0);
     hipDeviceSynchronize();
+#ifdef PP_TRACE
     unsigned long long t[8][4][2][5];
     hipMemcpyFromSymbol(t, HIP_SYMBOL(g_pp_trace), sizeof(t));
     const unsigned long long t0 = t[0][0][0][0];
@@ -54,6 +55,7 @@ int main(int argc, char** argv) {
             for (int k = 0; k < 7; ++k) printf(" %8lld", (long long)(ph[b][wv][k] - ph[0][0][0]));
             printf("\n");
         }
+#endif
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
     for (int it = 0; it < 20; ++it) theia_gemm_nt_pp_launch(&g, THEIA_BF16, 0);
