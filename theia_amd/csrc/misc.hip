@@ -99,11 +99,12 @@ extern "C" int theia_cast_permute3(const float* src, void* dst, int d0, int d1, 
     return THEIA_OK;
 }
 
-// Batched permuting cast: block -> (job, i, 32x32 or 16x64 tile of the (j, k) plane).  The tile goes through LDS so that the
+// Batched permuting cast: block -> (job, i, T1 x T2 tile of the (j, k) plane), T1*T2 = 4096 elements, 256 threads.
+// s2 == 1 (plain casts): straight 16-byte loads / 8-byte stores, no LDS.  Otherwise the tile goes through LDS so that the
 // source is read along whichever of j / k has the smaller source stride and the destination is written along k.
 template <typename T>
 __global__ __launch_bounds__(256) void cast_batch_kernel(const theia_cast_job_t* __restrict__ jobs, int njobs) {
-    __shared__ float tile[1024 + 64];
+    __shared__ float tile[4096 + 128];
     int lo = 0, hi = njobs - 1;  // last job with first_block <= blockIdx.x
     const int64_t bid = blockIdx.x;
     while (lo < hi) {
@@ -115,25 +116,47 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(const theia_cast_job_t*
     const int tk = (int)(r % jb.tiles2);
     r /= jb.tiles2;
     const int tj = (int)(r % jb.tiles1), i = (int)(r / jb.tiles1);
-    const int T1 = jb.tile1, T2 = jb.tile2;          // T1 * T2 == 1024
+    const int T1 = jb.tile1, T2 = jb.tile2;          // T1 * T2 == 4096, T2 a multiple of 4
     const int j0 = tj * T1, k0 = tk * T2;
     const float* __restrict__ src = jb.src + (int64_t)i * jb.s0;
+    const bool vec = jb.s2 == 1 && (jb.d2 & 3) == 0 && (jb.s1 & 3) == 0 && (jb.s0 & 3) == 0 && (jb.t1 & 3) == 0 && (jb.t0 & 3) == 0 &&
+                     (reinterpret_cast<uint64_t>(jb.src) & 15) == 0 && (reinterpret_cast<uint64_t>(jb.dst) & 15) == 0;
+    if (vec) {  // wave-uniform (per job)
+        const int Q2 = T2 >> 2;
+        for (int e = threadIdx.x; e < 1024; e += 256) {
+            const int kq = e % Q2, jj = e / Q2;
+            const int j = j0 + jj, k = k0 + kq * 4;
+            if (j < jb.d1 && k < jb.d2) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)j * jb.s1 + k);
+                const int64_t o = (int64_t)i * jb.t0 + (int64_t)j * jb.t1 + k;
+                if (jb.dst_f32 || sizeof(T) == 4) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(jb.dst) + o) = v;
+                } else {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(jb.dst) + o) = pk;
+                }
+            }
+        }
+        return;
+    }
     const int P2 = T2 + 1;                             // LDS pitch of a j-row
     if (jb.s1 < jb.s2) {                               // j is the fast source dimension
-        for (int e = threadIdx.x; e < 1024; e += 256) {
+        for (int e = threadIdx.x; e < 4096; e += 256) {
             const int jj = e % T1, kk = e / T1;
             const int j = j0 + jj, k = k0 + kk;
             if (j < jb.d1 && k < jb.d2) tile[jj * P2 + kk] = src[j * jb.s1 + k * jb.s2];
         }
     } else {
-        for (int e = threadIdx.x; e < 1024; e += 256) {
+        for (int e = threadIdx.x; e < 4096; e += 256) {
             const int kk = e % T2, jj = e / T2;
             const int j = j0 + jj, k = k0 + kk;
             if (j < jb.d1 && k < jb.d2) tile[jj * P2 + kk] = src[j * jb.s1 + k * jb.s2];
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 1024; e += 256) {
+    for (int e = threadIdx.x; e < 4096; e += 256) {
         const int kk = e % T2, jj = e / T2;
         const int j = j0 + jj, k = k0 + kk;
         if (j < jb.d1 && k < jb.d2) {
@@ -150,8 +173,8 @@ extern "C" int64_t theia_cast_batch_plan(theia_cast_job_t* jobs, int njobs) {
     for (int q = 0; q < njobs; ++q) {
         theia_cast_job_t& jb = jobs[q];
         if (jb.src == nullptr || jb.dst == nullptr || jb.d0 <= 0 || jb.d1 <= 0 || jb.d2 <= 0) return -1;
-        jb.tile1 = jb.d1 > 16 ? 32 : (jb.d1 > 4 ? 16 : (jb.d1 > 1 ? 4 : 1));
-        jb.tile2 = 1024 / jb.tile1;
+        jb.tile1 = jb.d1 > 32 ? 64 : (jb.d1 > 16 ? 32 : (jb.d1 > 4 ? 16 : (jb.d1 > 1 ? 4 : 1)));
+        jb.tile2 = 4096 / jb.tile1;
         jb.tiles1 = (jb.d1 + jb.tile1 - 1) / jb.tile1;
         jb.tiles2 = (jb.d2 + jb.tile2 - 1) / jb.tile2;
         jb.first_block = blocks;
