@@ -94,7 +94,10 @@ class _SideQueue:
     def __init__(self, device, enabled: bool = True):
         self.device = device
         self.enabled = enabled
-        self.stream = torch.cuda.Stream(device=device) if enabled else None
+        # lowest HIP stream priority: weight-gradient workgroups should fill CUs the main stream leaves idle, not compete
+        # with the data-gradient chain that is the critical path (THEIA_SIDE_PRIORITY overrides; larger = lower priority)
+        prio = int(os.environ.get("THEIA_SIDE_PRIORITY", "1"))
+        self.stream = torch.cuda.Stream(device=device, priority=prio) if enabled else None
         self.ws: Optional[torch.Tensor] = None
         self._dirty = False
         self._cb_queued = False
