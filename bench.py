@@ -85,17 +85,29 @@ def log(msg):
 
 def main():
     args = parse()
+    if os.environ.get("THEIA_BENCH_DEBUG"):  # dump every thread's stack if the run is still going after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["THEIA_BENCH_DEBUG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (see the docstring)")
+    # test hook (not a product path): THEIA_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 over gloo, so that the N>1 code path
+    # of this script (rendezvous, barriers, bucket all-reduces, max-over-ranks timing) can be smoke-tested on a 1-GPU box
+    # (gloo with device tensors and two processes per GPU dead-locks sporadically on this stack: use THEIA_BENCH_DEBUG=<s>)
+    one_device = os.environ.get("THEIA_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from theia_amd import ops
     from theia_amd.foundation_models.common import get_model_feature_size

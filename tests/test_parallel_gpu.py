@@ -1,0 +1,85 @@
+"""GPU, world_size = 2 on ONE device over gloo (RCCL refuses two ranks per GPU): the real data-parallel step -- HIP forward
+and backward of each rank's shard under TheiaDataParallel, bucket all-reduces issued on the reducer's stream behind the
+main-stream and weight-gradient-stream events, joined by the autograd completion callback -- must give every rank the
+single-process gradient of the whole batch (the oracle's, cf. golden G9 for the reference's own DDP run)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+# Opt-in (THEIA_TEST_DP2_ONE_GPU=1): gloo staging device tensors through the host with two processes sharing one GPU
+# dead-locks sporadically inside gloo's all_reduce on this stack (seen in bench.py's THEIA_BENCH_ONE_DEVICE smoke run, with
+# every rank parked in the same collective), so the test is kept out of the default GPU tier; the N>1 logic itself is
+# covered on CPU by tests/test_parallel_gloo.py and the RCCL path by bench.py under torch.distributed.run.
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180),
+              pytest.mark.skipif(os.environ.get("THEIA_TEST_DP2_ONE_GPU") != "1", reason="opt-in: flaky gloo-on-one-GPU rig")]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from oracle import theia_oracle as O  # checker only
+    from theia_amd.foundation_models.common import get_model_feature_size
+    from theia_amd.models.rvfm import RobotVisionFM
+    from theia_amd.parallel import TheiaDataParallel
+
+    dev = torch.device("cuda:0")
+    bb, teachers = "facebook/deit-tiny-patch16-224", O.TEACHER_SETS["cdiv"]
+    torch.manual_seed(100 + rank)  # different random init per rank: the broadcast must fix that
+    model = RobotVisionFM(backbone=bb, translator="lconv", translator_kwargs={"hidden_size_factor": 1.0},
+                          target_feature_sizes={t: get_model_feature_size(t, keep_spatial=True) for t in teachers}, precision="fp32")
+    if rank == 0:
+        model.load_state_dict(O.synth_params(bb, teachers, 0))
+    model = model.to(dev)
+    ddp = TheiaDataParallel(model)
+    B, per = 4, 2
+    images = O.synth_images(B, 0)
+    targets = O.synth_targets(B, teachers, 1)
+    sl = slice(rank * per, (rank + 1) * per)
+    for _ in range(2):  # second pass: accumulate=False overwrite + a second round of all-reduces
+        for p in model.parameters():
+            p.grad = None
+        losses = model.get_loss(ddp(images[sl]), {t: v[sl].to(dev) for t, v in targets.items()}, as_float=False)
+        (0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]).backward()
+    torch.cuda.synchronize()
+    got = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    if rank == 0:
+        params = O.synth_params(bb, teachers, 0)
+        _, _, ref, _ = O.train_step_grads(params, images, targets, bb, teachers, "cos_l1")
+        worst = ("", 0.0)
+        for n, g in got.items():
+            if "k_proj.bias" in n:  # analytically zero gradient
+                continue
+            r = ref[n]
+            e = float((g - r).norm() / (r.norm() + 1e-12))
+            if e > worst[1]:
+                worst = (n, e)
+        ret["worst"] = worst
+        ret["n"] = len(got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp2_on_one_gpu_matches_single_process_gradient():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret["n"] > 100
+    name, err = ret["worst"]
+    assert err < 2e-4, (name, err)

@@ -12,6 +12,7 @@ world_size-2 gloo processes; ``TheiaDataParallel`` wires it to a ``RobotVisionFM
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional
 
 import torch
@@ -32,6 +33,10 @@ class GradBucketReducer:
         engine's weight-gradient queue) -- have been reached; the all-reduce waits for both on its own stream."""
         if self.world == 1:
             return
+        # RCCL has an AVG reduction (no extra scale kernel); gloo (CPU tests, and the 2-ranks-on-one-GPU test) sums and
+        # the result is scaled when the bucket is waited for
+        avg = dist.get_backend(self.pg) == "nccl"
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         if flat.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=flat.device)
@@ -41,16 +46,20 @@ class GradBucketReducer:
                 self._side.wait_event(ev)
                 if also_after is not None:
                     self._side.wait_event(also_after)
-                work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
-            self._pending.append((work, flat, False))
-        else:  # gloo has no AVG: sum, then scale on completion
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            self._pending.append((work, flat, True))
+                # gloo stages device tensors through the host on its own pool streams; issued asynchronously from here it
+                # dead-locked sporadically in work.wait() (2 ranks sharing one GPU), so that test-only combination runs
+                # synchronously.  RCCL collectives are stream-ordered and stay asynchronous.
+                work = dist.all_reduce(flat, op=op, group=self.pg, async_op=avg or os.environ.get("THEIA_GLOO_ASYNC") == "1")
+            self._pending.append((work, flat, not avg))
+        else:
+            work = dist.all_reduce(flat, op=op, group=self.pg, async_op=True)
+            self._pending.append((work, flat, not avg))
 
     def finish(self) -> None:
         """Make the current stream (GPU) / the caller (CPU) wait for every outstanding bucket."""
         for work, flat, scale in self._pending:
-            work.wait()
+            if work is not None:
+                work.wait()
             if scale:
                 flat.div_(self.world)
         self._pending.clear()
