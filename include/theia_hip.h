@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define THEIA_ABI_VERSION 1
+#define THEIA_ABI_VERSION 2
 
 enum { THEIA_OK = 0, THEIA_ERR_INVALID = -1, THEIA_ERR_LAUNCH = -2, THEIA_ERR_UNSUPPORTED = -3 };
 enum { THEIA_F32 = 0, THEIA_BF16 = 1 };
@@ -122,9 +122,18 @@ typedef struct theia_wgrad_args {
     int32_t kslots;  /* weight slots in the slab row: row length = kslots*in_c */
     int32_t splits;
     theia_rowmap_t map;
+    /* optional fused bias gradient (the column sums of dY over the same rows; nn.Linear / Conv2d bias.grad):
+     * bias_out[n] (+)= sum_m dY[m, n].  bias_slabs: scratch of splits*N floats.  Only when theia_wgrad_fuses_bias()
+     * says the kernel that will run supports it (the ping-pong kernel feeds the dY fragments it already holds to one more
+     * MFMA against a tile of ones); otherwise leave bias_out NULL and use theia_colsum. */
+    float* bias_slabs;
+    float* bias_out;
+    int32_t bias_accumulate;
+    int32_t reserved;
 } theia_wgrad_args_t;
 
 int theia_gemm_wgrad(const theia_wgrad_args_t* args, int dtype, void* stream);
+int theia_wgrad_fuses_bias(const theia_wgrad_args_t* args, int dtype);
 /* recommended number of M-splits for (M, N, kslots*in_c) so that the launch fills 256 CUs */
 int theia_wgrad_splits(int M, int N, int Ktot);
 

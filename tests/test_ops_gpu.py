@@ -42,7 +42,7 @@ def rnd(x, dt):
 def test_library_loads_and_abi():
     from theia_amd import _native as N
     lib = N.lib()
-    assert lib.theia_abi_version() == 1
+    assert lib.theia_abi_version() == 2
     assert lib.theia_dtype_size(N.BF16) == 2
 
 
@@ -113,6 +113,17 @@ def test_linear_wgrad_and_colsum(dt, M, N, K):
     cs = torch.zeros(N, dtype=torch.float32, device=dev)
     ops.colsum(dy.to(dev, dt), cs, accumulate=False)
     assert relerr(cs, dyr.double().sum(0)) < 1e-5
+    # bias gradient through the weight-gradient entry point (fused into the ping-pong GEMM where it runs, colsum elsewhere),
+    # with accumulation, on a column slice of a wider dY (the q/k/v slices of dQKV)
+    wide = torch.zeros(M, N + 64, dtype=dt, device=dev)
+    wide[:, 64:] = dy.to(dev, dt)
+    gb = torch.full((N,), 0.25, dtype=torch.float32, device=dev)
+    g2 = torch.zeros(N, K, dtype=torch.float32, device=dev)
+    ops.linear_wgrad(wide[:, 64:], x.to(dev, dt), g2, accumulate=False, bias=(gb, True))
+    assert relerr(g2, ref) < 1e-4 * (1 if dt == torch.float32 else 10)
+    assert relerr(gb - 0.25, dyr.double().sum(0)) < 1e-5
+    ops.linear_wgrad(wide[:, 64:], x.to(dev, dt), g2, accumulate=False, bias=(gb, False))
+    assert relerr(gb, dyr.double().sum(0)) < 1e-5
 
 
 def _nhwc(a):
@@ -183,9 +194,11 @@ def test_conv_family_fwd_dgrad_wgrad(dt, kind, C):
     assert relerr(gw, Wr.grad) < TOL[dt]
     # ... and the engine's entry point (stride-2 transposed convs reduce over input pixels instead), with accumulation
     gw2 = torch.full((C, C, 3, 3), 0.5, dtype=torch.float32, device=dev)
-    ops.conv_wgrad(plan, gyd.view(b, -1), xd.view(b, -1), b, C, gw2, accumulate=True)
+    gb2 = torch.full((C,), 0.5, dtype=torch.float32, device=dev)
+    ops.conv_wgrad(plan, gyd.view(b, -1), xd.view(b, -1), b, C, gw2, accumulate=True, bias=(gb2, True))
     assert plan.wgrad_swapped == kind.startswith("convT_s2")
     assert relerr(gw2 - 0.5, Wr.grad) < TOL[dt]
+    assert relerr(gb2 - 0.5, gyr.double().sum((0, 1, 2))) < 1e-5
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

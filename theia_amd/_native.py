@@ -62,6 +62,7 @@ class WgradArgs(C.Structure):
         ("dy", C.c_void_p), ("a", C.c_void_p), ("slabs", C.c_void_p),
         ("M", C.c_int32), ("N", C.c_int32), ("ldo", C.c_int32), ("kslots", C.c_int32), ("splits", C.c_int32),
         ("map", RowMap),
+        ("bias_slabs", C.c_void_p), ("bias_out", C.c_void_p), ("bias_accumulate", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -73,6 +74,7 @@ _SIGNATURES = {
     "theia_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_void_p]),
     "theia_gemm_nt_tile": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "theia_gemm_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_int, C.c_void_p]),
+    "theia_wgrad_fuses_bias": (C.c_int, [C.POINTER(WgradArgs), C.c_int]),
     "theia_wgrad_splits": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "theia_wgrad_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
                                      C.c_int64, C.c_int, C.c_void_p]),
@@ -134,7 +136,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if handle.theia_abi_version() != 1:
+        if handle.theia_abi_version() != 2:
             raise TheiaNativeError("libtheia_hip.so ABI version mismatch")
         _lib = handle
     return _lib

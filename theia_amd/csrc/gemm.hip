@@ -518,6 +518,7 @@ static int launch_wgrad(const theia_wgrad_args_t* a, hipStream_t stream) {
 }
 
 int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream);  // gemm_wgrad_pp.hip
+bool theia_gemm_wgrad_pp_supported(const theia_wgrad_args_t* a);
 
 static bool wgrad_use_pp() {
     static int v = -1;
@@ -548,8 +549,14 @@ extern "C" int theia_wgrad_splits(int M, int N, int Ktot) {
     return s;
 }
 
+extern "C" int theia_wgrad_fuses_bias(const theia_wgrad_args_t* a, int dtype) {
+    return a != nullptr && dtype == THEIA_BF16 && wgrad_use_pp() && theia_gemm_wgrad_pp_supported(a) ? 1 : 0;
+}
+
 extern "C" int theia_gemm_wgrad(const theia_wgrad_args_t* a, int dtype, void* stream) {
     THEIA_CHECK_ARG(a != nullptr, "theia_gemm_wgrad: null args");
+    THEIA_CHECK_ARG(a->bias_out == nullptr || (a->bias_slabs != nullptr && theia_wgrad_fuses_bias(a, dtype)),
+                    "theia_gemm_wgrad: bias_out needs bias_slabs and a kernel that fuses it (theia_wgrad_fuses_bias)");
     THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16, "theia_gemm_wgrad: bad dtype %d", dtype);
     THEIA_CHECK_ARG(a->dy && a->a && a->slabs, "theia_gemm_wgrad: null pointer");
     THEIA_CHECK_ARG(a->M > 0 && a->M < (1 << 24) && a->N > 0 && a->splits >= 1, "theia_gemm_wgrad: bad shape (M must be < 2^24)");

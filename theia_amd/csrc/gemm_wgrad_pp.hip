@@ -111,6 +111,13 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     for (int i = 0; i < FN; ++i)
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = (gt_f32x4){0.f, 0.f, 0.f, 0.f};
+    // fused bias gradient: the workgroups of the first (tap, c) tile column also sum dY over their rows -- the dY fragments
+    // against a fragment of ones, 4 more MFMAs per half-step in the four waves that own the first 128 c columns
+    const bool do_bias = p.bias_slabs != nullptr && tk == 0 && wm == 0;  // wave-uniform
+    gt_f32x4 bacc[FN];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) bacc[i] = (gt_f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
 
     // prologue: half-steps 0..2 (rows past the split end read zeros)
 #pragma unroll
@@ -152,6 +159,10 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
                 if (j == 0) issue_row(0, nslot);
                 if (j == 4) issue_row(1, nslot);
             }
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < FN; ++i) GtMma<bf16_t>::run(bacc[i], ones, fb[i]);
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -168,6 +179,13 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     const int64_t krow = (int64_t)p.kslots * mp.in_c;
     float* slab = p.slabs + (int64_t)split * p.N * krow;
     const int q = lane & 15, g = lane >> 4;
+    if (do_bias && g == 0) {  // every c row of the ones-product holds the column sum: take row 0 (lanes 0-15, register 0)
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + q;
+            if (n < p.N) p.bias_slabs[(int64_t)split * p.N + n] = bacc[i][0];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
         const int n = n0 + wn * 64 + i * 16 + q;
@@ -179,9 +197,21 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     }
 }
 
+// out[n] (+)= sum_s part[s*N + n], fixed order
+__global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ part, int splits, int N, float* __restrict__ out,
+                                                                int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int q = 0; q < splits; ++q) s += part[(int64_t)q * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+bool theia_gemm_wgrad_pp_supported(const theia_wgrad_args_t* a) { return a->map.in_c % 256 == 0 && a->N >= 128; }
+
 // bf16 only; requires in_c % 256 == 0.  Returns THEIA_ERR_UNSUPPORTED when the shape does not qualify.
 int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) {
-    if (a->map.in_c % 256 != 0 || a->N < 128) return THEIA_ERR_UNSUPPORTED;
+    if (!theia_gemm_wgrad_pp_supported(a)) return THEIA_ERR_UNSUPPORTED;
     constexpr int lds = 4 * 2 * 32 * 512;
     static bool attr_set = false;
     if (!attr_set) {
@@ -191,5 +221,10 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
     const int tiles = cdiv_i(a->N, 256) * a->map.ntaps * (a->map.in_c / 256);
     hipLaunchKernelGGL(gemm_wgrad_pp_kernel, dim3(tiles * a->splits), dim3(512), lds, stream, *a);
     THEIA_CHECK_LAUNCH("theia_gemm_wgrad(pp)");
+    if (a->bias_out != nullptr) {
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv_i(a->N, 256)), dim3(256), 0, stream, a->bias_slabs, a->splits, a->N,
+                           a->bias_out, a->bias_accumulate);
+        THEIA_CHECK_LAUNCH("theia_gemm_wgrad(pp bias)");
+    }
     return THEIA_OK;
 }

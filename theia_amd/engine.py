@@ -420,19 +420,17 @@ class StudentEngine:
             raise TypeError(f"gradient dtype {dz.dtype} does not match the engine's compute dtype {T}")
         wsz = max(N.lib().theia_layernorm_bwd_workspace_bytes(M, D) // 4, N.lib().theia_colsum_workspace_bytes(M, F) // 4,
                   N.lib().theia_colsum_workspace_bytes(b, NTOK * D) // 4,
-                  max(ops.wgrad_splits(M, n_, k_) * n_ * k_ for n_, k_ in ((D, F), (F, D), (D, D), (D, 768))))
+                  max(ops.wgrad_splits(M, n_, k_) * n_ * (k_ + 1) for n_, k_ in ((D, F), (F, D), (D, D), (D, 768))))  # slabs + bias partials
         ws = self.ws(wsz, dev)
         side = self._side_queue(dev, wsz)
 
         # weight / bias gradients only feed the optimizer: they run on a side HIP stream so that their workgroups fill the
         # CUs left idle by the tail rounds and epilogues of the data-gradient chain on the main stream (and vice versa)
-        def wgrad(dy, x, p):
-            g, acc = self._grad(p)
-            side.run(lambda: ops.linear_wgrad(dy, x, g, acc, side.ws), dy, x)
-
-        def bgrad(dy, p):
-            g, acc = self._grad(p)
-            side.run(lambda: ops.colsum(dy, g, acc, side.ws), dy)
+        def wgrad(dy, x, pw, pb):
+            """weight and bias gradient of one nn.Linear: one GEMM launch (+ slab reduce) on the side stream"""
+            gw_, accw_ = self._grad(pw)
+            gb_, accb_ = self._grad(pb)
+            side.run(lambda: ops.linear_wgrad(dy, x, gw_, accw_, side.ws, bias=(gb_, accb_)), dy, x)
 
         hL, meanf, rstdf = saved["final"]
         gw, accw = self._grad(vit.layernorm.weight)
@@ -446,12 +444,10 @@ class StudentEngine:
             (h, mean1, rstd1, a, qkv, o, lse, h1, mean2, rstd2, m, pre, act) = saved["layers"][i]
             saved["layers"][i] = None
             # h2 = h1 + fc2(act)
-            wgrad(dh, act, L.mlp.fc2.weight)
-            bgrad(dh, L.mlp.fc2.bias)
+            wgrad(dh, act, L.mlp.fc2.weight, L.mlp.fc2.bias)
             dpre = ops.linear(dh, oc[f"l{i}.w2T"], None, act=N.ACT_MUL_DGELU, aux_in=pre)
             del act, pre
-            wgrad(dpre, m, L.mlp.fc1.weight)
-            bgrad(dpre, L.mlp.fc1.bias)
+            wgrad(dpre, m, L.mlp.fc1.weight, L.mlp.fc1.bias)
             dm = ops.linear(dpre, oc[f"l{i}.w1T"])
             del dpre
             g2w, acc = self._grad(L.layernorm_after.weight)
@@ -459,15 +455,13 @@ class StudentEngine:
             dh1 = ops.layernorm_bwd(dm, h1, L.layernorm_after.weight, mean2, rstd2, dh, g2w, g2b, acc, ws)
             del dm, dh
             # h1 = h + o_proj(o)
-            wgrad(dh1, o, L.attention.o_proj.weight)
-            bgrad(dh1, L.attention.o_proj.bias)
+            wgrad(dh1, o, L.attention.o_proj.weight, L.attention.o_proj.bias)
             do = ops.linear(dh1, oc[f"l{i}.woT"])
             dqkv = ops.attention_bwd(qkv, o, do, lse, b, NTOK, nh, ws)
             del do
             for j, prj in enumerate((L.attention.q_proj, L.attention.k_proj, L.attention.v_proj)):
                 sl = dqkv[:, j * D:(j + 1) * D]
-                wgrad(sl, a, prj.weight)
-                bgrad(sl, prj.bias)
+                wgrad(sl, a, prj.weight, prj.bias)
             da = ops.linear(dqkv, oc[f"l{i}.wqkvT"])
             del dqkv
             g1w, acc = self._grad(L.layernorm_before.weight)
@@ -569,8 +563,8 @@ class StudentEngine:
             Ct = dp.shape[-1]
             E3 = s2 * s2 * C
             chw_need = N.lib().theia_layernorm_chw_workspace_bytes(b, E3) // 4
-            conv_slabs = max(ops.conv_wgrad_splits(self._plan(k), b, C) for k in ("pad", "conv16", "up31", "up64")) * 9 * C * C
-            lin_slabs = ops.wgrad_splits(b * s2 * s2, Ct, C) * Ct * C
+            conv_slabs = max(ops.conv_wgrad_splits(self._plan(k), b, C) for k in ("pad", "conv16", "up31", "up64")) * (9 * C * C + C)
+            lin_slabs = ops.wgrad_splits(b * s2 * s2, Ct, C) * Ct * (C + 1)
             ws = self.ws(max(chw_need + 2 * E3 + 64, conv_slabs, lin_slabs,
                              N.lib().theia_colsum_workspace_bytes(b * s2 * s2, max(C, Ct)) // 4 + 64), dev)
             dp = dp.contiguous().view(b * s2 * s2, Ct)
@@ -585,10 +579,7 @@ class StudentEngine:
                 gw, accw = self._grad(mod.weight)
                 gb, accb = self._grad(mod.bias)
 
-                def task():
-                    ops.linear_wgrad(dy, x, gw, accw, side.ws)
-                    ops.colsum(dy, gb, accb, side.ws)
-                side.run(task, dy, x)
+                side.run(lambda: ops.linear_wgrad(dy, x, gw, accw, side.ws, bias=(gb, accb)), dy, x)
 
             def conv_grads(dy2d, x, mod, plan, mtot):
                 """dy2d [M_total, C] is the conv output gradient, x the conv input (flat NHWC); side stream like the ViT's."""
@@ -597,10 +588,7 @@ class StudentEngine:
                 gb, accb = self._grad(mod.bias)
                 gw, accw = self._grad(mod.weight)
 
-                def task():
-                    ops.colsum(dy2d, gb, accb, side.ws)
-                    ops.conv_wgrad(plan, dy2d, x, b, C, gw, accw, side.ws)
-                side.run(task, dy2d, x)
+                side.run(lambda: ops.conv_wgrad(plan, dy2d, x, b, C, gw, accw, side.ws, bias=(gb, accb)), dy2d, x)
 
             def ln_bwd(dy, x, stats, idx, hw, relu_mask):
                 E = hw * hw * C

@@ -147,20 +147,36 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
                    aux_in, aux_out)
 
 
-def gemm_wgrad(dy: torch.Tensor, a: torch.Tensor, slabs: torch.Tensor, M: int, Nn: int, ldo: int, kslots: int, splits: int,
-               rmap: RowMap) -> None:
+def _wgrad_args(dy: torch.Tensor, a: torch.Tensor, slabs: torch.Tensor, M: int, Nn: int, ldo: int, kslots: int, splits: int,
+                rmap: RowMap) -> WgradArgs:
     g = WgradArgs()
     g.dy, g.a, g.slabs = dy.data_ptr(), a.data_ptr(), slabs.data_ptr()
     g.M, g.N, g.ldo, g.kslots, g.splits = M, Nn, ldo, kslots, splits
     g.map = rmap
+    return g
+
+
+def gemm_wgrad(dy: torch.Tensor, a: torch.Tensor, slabs: torch.Tensor, M: int, Nn: int, ldo: int, kslots: int, splits: int,
+               rmap: RowMap, bias_out: Optional[torch.Tensor] = None, bias_accumulate: bool = False,
+               bias_slabs: Optional[torch.Tensor] = None) -> bool:
+    """slab[s][n][slot*in_c + c] = sum_{m in split s} dy[m, n] * a[m, (tap, c)].  With bias_out (f32 [N]) the bias gradient
+    bias_out (+)= colsum(dy) is produced by the same launch when the kernel supports it (returns True); otherwise the
+    caller has to run colsum (returns False)."""
+    g = _wgrad_args(dy, a, slabs, M, Nn, ldo, kslots, splits, rmap)
+    fused = False
+    if bias_out is not None and bias_slabs is not None and N.lib().theia_wgrad_fuses_bias(g, _dt(dy)):
+        assert bias_slabs.numel() >= splits * Nn and bias_out.dtype == torch.float32
+        g.bias_slabs, g.bias_out, g.bias_accumulate = bias_slabs.data_ptr(), bias_out.data_ptr(), int(bias_accumulate)
+        fused = True
     if WGRAD_PROFILE is not None:  # tuning aid (bench.py THEIA_BENCH_GEMM_TABLE): HIP events on the launch stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         N.check(N.lib().theia_gemm_wgrad(g, _dt(dy), N.stream_ptr()), "theia_gemm_wgrad")
         e1.record()
         WGRAD_PROFILE.append((e0, e1, 2.0 * M * Nn * kslots * rmap.in_c, f"s{splits}", (M, Nn, kslots * rmap.in_c)))
-        return
+        return fused
     N.check(N.lib().theia_gemm_wgrad(g, _dt(dy), N.stream_ptr()), "theia_gemm_wgrad")
+    return fused
 
 
 def wgrad_splits(M: int, Nn: int, Ktot: int) -> int:
@@ -180,8 +196,9 @@ def conv_wgrad_splits(plan: ConvPlan, b: int, C: int) -> int:
 
 
 def conv_wgrad(plan: ConvPlan, dy: torch.Tensor, x: torch.Tensor, b: int, C: int, grad_w: torch.Tensor, accumulate: bool,
-               ws: Optional[torch.Tensor] = None) -> None:
-    """grad_w (reference layout, f32) (+)= weight gradient of one 3x3 (transposed) convolution.
+               ws: Optional[torch.Tensor] = None, bias: Optional[Tuple[torch.Tensor, bool]] = None) -> None:
+    """grad_w (reference layout, f32) (+)= weight gradient of one 3x3 (transposed) convolution; bias = (grad_b, accumulate)
+    also produces the bias gradient colsum(dy) (inside the GEMM launch when it can, else with theia_colsum).
     dy: output gradient, flat NHWC [b, OH*OH*C]; x: the convolution's input (flat NHWC, possibly strided per the plan).
 
     Stride-2 transposed convolutions reduce over INPUT pixels: dW[ci, co, tap] = sum_{b,i,j} x[b,i,j,ci] * dy[b, 2i-p+ky, 2j-p+kx, co]
@@ -190,31 +207,42 @@ def conv_wgrad(plan: ConvPlan, dy: torch.Tensor, x: torch.Tensor, b: int, C: int
     output-parity class with 1, 2, 2 and 4 live taps (27..108 workgroups each on 256 CUs)."""
     splits = conv_wgrad_splits(plan, b, C)
     need = splits * C * 9 * C
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.float32, device=dy.device)
+    extra = splits * C
+    if ws is None or ws.numel() < need + extra:
+        ws = torch.empty(need + extra, dtype=torch.float32, device=dy.device)
     slabs = ws[:need]
+    fused = False
     if plan.wgrad_swapped:
         rmap, mpi = plan.dgrad
         gemm_wgrad(x, dy, slabs, b * mpi, C, C, 9, splits, rmap)
         wgrad_reduce(slabs, splits, C, 9, C, grad_w, 9 * C, 1, 9, accumulate)  # slab[ci][tap][co] -> W[ci, co, ky, kx]
     else:
-        for rmap, mpi in plan.fwd:
-            gemm_wgrad(dy, x, slabs, b * mpi, C, C, 9, splits, rmap)
+        for k, (rmap, mpi) in enumerate(plan.fwd):
+            one = len(plan.fwd) == 1 and bias is not None
+            fused = gemm_wgrad(dy, x, slabs, b * mpi, C, C, 9, splits, rmap, bias[0] if one else None, bias[1] if one else False,
+                               ws[need:need + extra] if one else None)
         sn, ss, sc = plan.grad_strides
         wgrad_reduce(slabs, splits, C, 9, C, grad_w, sn, ss, sc, accumulate)
+    if bias is not None and not fused:
+        colsum(dy.view(-1, C), bias[0], bias[1], ws)
 
 
 def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, grad_w: torch.Tensor, accumulate: bool,
-                 ws: Optional[torch.Tensor] = None) -> None:
-    """grad_w[N,K] (+)= dy[M,N]^T @ x[M,K]."""
+                 ws: Optional[torch.Tensor] = None, bias: Optional[Tuple[torch.Tensor, bool]] = None) -> None:
+    """grad_w[N,K] (+)= dy[M,N]^T @ x[M,K];  bias = (grad_b, accumulate): grad_b[N] (+)= colsum(dy), inside the GEMM launch
+    when the kernel supports it, else with theia_colsum."""
     M, Nn = dy.shape
     K = x.shape[1]
     splits = wgrad_splits(M, Nn, K)
     need = splits * Nn * K
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.float32, device=dy.device)
-    gemm_wgrad(dy, x, ws, M, Nn, dy.stride(0), 1, splits, rm_plain(K, x.stride(0), dy.stride(0)))
+    extra = splits * Nn
+    if ws is None or ws.numel() < need + extra:
+        ws = torch.empty(need + extra, dtype=torch.float32, device=dy.device)
+    fused = gemm_wgrad(dy, x, ws, M, Nn, dy.stride(0), 1, splits, rm_plain(K, x.stride(0), dy.stride(0)),
+                       bias[0] if bias is not None else None, bias[1] if bias is not None else False, ws[need:need + extra])
     wgrad_reduce(ws, splits, Nn, 1, K, grad_w, K, 0, 1, accumulate)
+    if bias is not None and not fused:
+        colsum(dy, bias[0], bias[1], ws)
 
 
 def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool, ws: Optional[torch.Tensor] = None) -> None:
