@@ -8,7 +8,9 @@
 // ================================================================================================
 constexpr int LN_MAXV = 4;  // 8-element vectors per lane
 
-template <typename T>
+// NV = 8-element vectors per lane: 2 for D <= 1024 (the ViT widths), else NV -- the row and, in backward, the per-lane
+// dgamma/dbeta accumulators live in registers, so NV sets the register count (backward: 226 VGPRs at NV = 4).
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_row_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ y,
                                                          float* __restrict__ mean, float* __restrict__ rstd, int64_t M,
@@ -18,10 +20,10 @@ __global__ __launch_bounds__(256) void ln_row_fwd_kernel(const T* __restrict__ x
     const float invD = 1.0f / (float)D;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * 4) {
         const T* xr = x + row * D;
-        float v[LN_MAXV][8];
+        float v[NV][8];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int vi = lane + 64 * i;
             if (vi < nv) {
                 load8(xr + vi * 8, v[i]);
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(256) void ln_row_fwd_kernel(const T* __restrict__ x
         const float mu = wave_sum(s) * invD;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int vi = lane + 64 * i;
             if (vi < nv) {
 #pragma unroll
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void ln_row_fwd_kernel(const T* __restrict__ x
         const float var = wave_sum(q) * invD;
         const float rs = 1.0f / sqrtf(var + eps);
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int vi = lane + 64 * i;
             if (vi < nv) {
                 float g8[8], b8[8], o[8];
@@ -70,11 +72,14 @@ extern "C" int theia_layernorm_fwd(const void* x, const float* gamma, const floa
     int blocks = (int)((M + 3) / 4);
     if (blocks > 8192) blocks = 8192;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == THEIA_BF16)
-        hipLaunchKernelGGL(ln_row_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
-    else if (dtype == THEIA_F32)
-        hipLaunchKernelGGL(ln_row_fwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps);
-    else
+    const bool small = D <= 1024;
+    if (dtype == THEIA_BF16) {
+        if (small) hipLaunchKernelGGL((ln_row_fwd_kernel<bf16_t, 2>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
+        else hipLaunchKernelGGL((ln_row_fwd_kernel<bf16_t, LN_MAXV>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
+    } else if (dtype == THEIA_F32) {
+        if (small) hipLaunchKernelGGL((ln_row_fwd_kernel<float, 2>), dim3(blocks), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps);
+        else hipLaunchKernelGGL((ln_row_fwd_kernel<float, LN_MAXV>), dim3(blocks), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps);
+    } else
         THEIA_CHECK_ARG(false, "theia_layernorm_fwd: bad dtype %d", dtype);
     THEIA_CHECK_LAUNCH("theia_layernorm_fwd");
     return THEIA_OK;
@@ -82,7 +87,7 @@ extern "C" int theia_layernorm_fwd(const void* x, const float* gamma, const floa
 
 // backward: dx per row (wave); dgamma/dbeta accumulated per lane over the rows this wave visits, then
 // block-reduced through LDS and written as one partial row per block; a second kernel sums the partials.
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_row_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const T* __restrict__ dres,
@@ -91,9 +96,9 @@ __global__ __launch_bounds__(256) void ln_row_bwd_kernel(const T* __restrict__ d
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 3;
     const float invD = 1.0f / (float)D;
-    float ag[LN_MAXV][8], ab[LN_MAXV][8], g8[LN_MAXV][8];
+    float ag[NV][8], ab[NV][8], g8[NV][8];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int vi = lane + 64 * i;
 #pragma unroll
         for (int j = 0; j < 8; ++j) ag[i][j] = ab[i][j] = g8[i][j] = 0.f;
@@ -101,15 +106,16 @@ __global__ __launch_bounds__(256) void ln_row_bwd_kernel(const T* __restrict__ d
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
-        float xh[LN_MAXV][8], gy[LN_MAXV][8];
-        float s1 = 0.f, s2 = 0.f;
+        float xh[NV][8], gy[NV][8], rr[NV][8];  // rr: the residual-stream gradient, requested with the row (not after the
+        float s1 = 0.f, s2 = 0.f;                 // reduction: a second exposed memory latency per row)
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int vi = lane + 64 * i;
             if (vi < nv) {
                 float xv[8], dv[8];
                 load8(x + row * D + vi * 8, xv);
                 load8(dy + row * D + vi * 8, dv);
+                if (dres != nullptr) load8(dres + row * D + vi * 8, rr[i]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     xh[i][j] = (xv[j] - mu) * rs;
@@ -123,17 +129,15 @@ __global__ __launch_bounds__(256) void ln_row_bwd_kernel(const T* __restrict__ d
         }
         const float m1 = wave_sum(s1) * invD, m2 = wave_sum(s2) * invD;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int vi = lane + 64 * i;
             if (vi < nv) {
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = rs * (gy[i][j] - m1 - xh[i][j] * m2);
                 if (dres != nullptr) {
-                    float r8[8];
-                    load8(dres + row * D + vi * 8, r8);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] += r8[j];
+                    for (int j = 0; j < 8; ++j) o[j] += rr[i][j];
                 }
                 store8(dx + row * D + vi * 8, o);
             }
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void ln_row_bwd_kernel(const T* __restrict__ d
     }
     float* mine = red + wave * 2 * D;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int vi = lane + 64 * i;
         if (vi < nv) {
 #pragma unroll
@@ -156,21 +160,27 @@ __global__ __launch_bounds__(256) void ln_row_bwd_kernel(const T* __restrict__ d
         part[(int64_t)blockIdx.x * 2 * D + i] = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
 }
 
-// out[c] (+)= sum_p part[p][c]  for c in [0, ncol); deterministic order
-// 64 columns x 4 part lanes per block (a thread-per-column loop over hundreds of partial rows is latency-bound)
+// out[c] (+)= sum_p part[p][c]  for c in [0, ncol); deterministic order.
+// COLS columns x (256 / COLS) part lanes per block: a thread-per-column loop over hundreds of partial rows is latency-bound,
+// so the row-LN reduction (512 partial rows, 1536 columns) uses 16 x 16 (96 blocks, 32 loads per thread: 24 -> ~8 us) and the
+// wide whole-sample reductions (few partial rows, millions of columns) 64 x 4.
+template <int COLS>
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ part, int nparts, int ncol, int64_t pitch,
                                                              float* __restrict__ out0, float* __restrict__ out1, int split,
                                                              int accumulate) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    constexpr int LANES = 256 / COLS;
+    __shared__ float red[LANES][COLS];
+    const int cl = threadIdx.x % COLS, pl = threadIdx.x / COLS;
+    const int c = blockIdx.x * COLS + cl;
     float s = 0.f;
     if (c < ncol)
-        for (int p = pl; p < nparts; p += 4) s += part[(int64_t)p * pitch + c];
+        for (int p = pl; p < nparts; p += LANES) s += part[(int64_t)p * pitch + c];
     red[pl][cl] = s;
     __syncthreads();
     if (pl == 0 && c < ncol) {
-        s = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        s = 0.f;
+#pragma unroll
+        for (int q = 0; q < LANES; ++q) s += red[q][cl];
         float* dst = c < split ? out0 + c : out1 + (c - split);
         *dst = accumulate ? *dst + s : s;
     }
@@ -194,14 +204,17 @@ extern "C" int theia_layernorm_bwd(const void* dy, const void* x, const float* g
     const int blocks = ln_bwd_blocks(M);
     const size_t lds = 4 * 2 * D * sizeof(float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == THEIA_BF16)
-        hipLaunchKernelGGL(ln_row_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dresid, (bf16_t*)dx, workspace, M, D);
-    else if (dtype == THEIA_F32)
-        hipLaunchKernelGGL(ln_row_bwd_kernel<float>, dim3(blocks), dim3(256), lds, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dresid, (float*)dx, workspace, M, D);
-    else
+    const bool small = D <= 1024;
+    if (dtype == THEIA_BF16) {
+        if (small) hipLaunchKernelGGL((ln_row_bwd_kernel<bf16_t, 2>), dim3(blocks), dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dresid, (bf16_t*)dx, workspace, M, D);
+        else hipLaunchKernelGGL((ln_row_bwd_kernel<bf16_t, LN_MAXV>), dim3(blocks), dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dresid, (bf16_t*)dx, workspace, M, D);
+    } else if (dtype == THEIA_F32) {
+        if (small) hipLaunchKernelGGL((ln_row_bwd_kernel<float, 2>), dim3(blocks), dim3(256), lds, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dresid, (float*)dx, workspace, M, D);
+        else hipLaunchKernelGGL((ln_row_bwd_kernel<float, LN_MAXV>), dim3(blocks), dim3(256), lds, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dresid, (float*)dx, workspace, M, D);
+    } else
         THEIA_CHECK_ARG(false, "theia_layernorm_bwd: bad dtype %d", dtype);
     THEIA_CHECK_LAUNCH("theia_layernorm_bwd");
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, workspace, blocks, 2 * D,
+    hipLaunchKernelGGL(partial_reduce_kernel<16>, dim3((2 * D + 15) / 16), dim3(256), 0, s, workspace, blocks, 2 * D,
                        (int64_t)2 * D, dgamma, dbeta, D, accumulate);
     THEIA_CHECK_LAUNCH("theia_layernorm_bwd(reduce)");
     return THEIA_OK;
@@ -404,7 +417,7 @@ extern "C" int theia_layernorm_chw_bwd(const void* dy, const void* x, const floa
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_bwd(dx)");
     // reduce partials: columns [0,E) -> dgamma, [E,2E) -> dbeta
     const int64_t ncol = 2 * E;
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((ncol + 63) / 64)), dim3(256), 0, s, parts, ng, (int)ncol,
+    hipLaunchKernelGGL(partial_reduce_kernel<64>, dim3((unsigned)((ncol + 63) / 64)), dim3(256), 0, s, parts, ng, (int)ncol,
                        (int64_t)2 * E, dgamma, dbeta, (int)E, accumulate);
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_bwd(reduce)");
     return THEIA_OK;

@@ -94,9 +94,9 @@ class _SideQueue:
     def __init__(self, device, enabled: bool = True):
         self.device = device
         self.enabled = enabled
-        # lowest HIP stream priority: weight-gradient workgroups should fill CUs the main stream leaves idle, not compete
-        # with the data-gradient chain that is the critical path (THEIA_SIDE_PRIORITY overrides; larger = lower priority)
-        prio = int(os.environ.get("THEIA_SIDE_PRIORITY", "1"))
+        # HIP exposes two stream priorities here (0 = default/low, -1 = high); the queue stays at the default.  A/B on the
+        # bench (THEIA_SIDE_PRIORITY=-1 / 0): no difference, the CU share of co-running kernels is set by their LDS footprint.
+        prio = int(os.environ.get("THEIA_SIDE_PRIORITY", "0"))
         self.stream = torch.cuda.Stream(device=device, priority=prio) if enabled else None
         self.ws: Optional[torch.Tensor] = None
         self._dirty = False
