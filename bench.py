@@ -254,8 +254,20 @@ def main():
             iso_tf = achieved
         kname = (f"gemm_nt_pp_kernel<{pfx}> (theia_gemm_nt, 256x256 ping-pong tile)" if dom_var == "256x256"
                  else f"gemm_nt_kernel<{pfx},{dom_var.replace('x', ',')}> (theia_gemm_nt)")
+        # HBM-side bytes per launch of this kernel: PMC numbers cannot be collected inside a timed run, so they come from the
+        # committed summary of tools/pmc_bench_traffic.sh (FETCH_SIZE x2 per the guide's gfx950 correction + WRITE_SIZE,
+        # mean over the launches of the same bench step); null when the file is absent
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic.json")
+        if dom_var == "256x256" and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = [k for k in tj if k.startswith("gemm_nt_pp_kernel") and (("bf16" in k) == (pfx == "bf16"))]
+                traffic = tj[key[0]]["hbm_bytes_per_launch"] if key else None
+            except Exception:  # a malformed summary must not break the benchmark
+                traffic = None
         roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK / 1e12,
-                    "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4), "traffic": traffic,
                     "launches_per_step": len(dom) // NP, "avg_launch_us": round(tsum / len(dom) * 1e6, 1),
                     "flops_per_launch": round(fsum / len(dom)),
                     "achieved_isolated": round(iso_tf, 1), "frac_isolated": round(iso_tf * 1e12 / MFMA_BF16_PEAK, 4),

@@ -1,0 +1,27 @@
+#!/bin/bash
+# HBM-side traffic of every kernel of the default bench step: two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot
+# share a pass; kernel-trace only), then tools/pmc_summary.py.  usage: tools/pmc_bench_traffic.sh <outdir>
+set -u
+OUT=$1
+cd /tmp && export TMPDIR=/tmp
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $OUT
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o pmc -- \
+      python $REPO/bench.py --steps 2 --warmup 1 --no-roofline --no-cpu-baseline > $OUT/$c.log 2>&1
+done
+python $REPO/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
+python - "$OUT/summary.txt" <<'PY'
+import json, re, sys
+txt = open(sys.argv[1]).read()
+out = {}
+for block in re.split(r"\n(?=\S)", txt):
+    lines = block.strip().split("\n")
+    vals = {m.group(1): float(m.group(2)) for m in (re.match(r"\s+(\w+)\s+([\d.]+)", l) for l in lines[1:]) if m}
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        # guide (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts wide streaming reads at half their bytes on gfx950 -> x2; KB units
+        out[lines[0].strip()] = {"fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
+                                 "hbm_bytes_per_launch": round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)}
+json.dump(out, open(sys.argv[1].replace("summary.txt", "traffic.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if "gemm" in k}, indent=1))
+PY
