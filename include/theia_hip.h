@@ -249,6 +249,12 @@ int theia_token_select(const void* x, float* out, int b, int n, int D, int disc,
  * (dataset/data_utils.py:342-355,374-379): x bf16 [rows, C] -> f32 [rows, C] */
 int theia_feature_norm_bf16(const uint16_t* x, const float* mean, const float* std, float* out, int64_t rows,
                             int C, void* stream);
+/* Teacher-feature ingest, whole batch: x_chw [b, C, HW] bf16 exactly as stored by the feature extractor (safetensors
+ * "embedding", feature_extraction_core/models.py:55-97) -> out [b, HW, C] f32 = float(bf16(bf16(x - bf16(mean[c])) / bf16(std[c])))
+ * (decode_sample's rearrange, dataset/data_utils.py:152-155; normalize_feature :342-355 with bf16 stats :374-379; .float()
+ * scripts/train/train_rvfm.py:112-114).  mean == std == NULL: transpose + widen only. */
+int theia_feature_ingest_bf16(const uint16_t* x_chw, const float* mean, const float* std, float* out, int b, int C, int HW,
+                              void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * elementwise helpers on `dtype` buffers

@@ -225,6 +225,26 @@ def gen_g8():
                         x_bits=x.view(torch.int16).numpy(), mean=mean.numpy(), std=std.numpy(), y=y.numpy())
 
 
+def gen_g11():
+    """Teacher-feature ingest: the reference's decode_sample branch for ".safetensors" keys (data_utils.py:150-155:
+    sft_load -> rearrange "c h w -> (h w) c" -> feature_transform) followed by .float() (train_rvfm.py:112-114).
+    data_utils itself cannot be imported here (webdataset / cv2 are absent), so its three lines are evaluated with the same
+    library calls (safetensors.torch.load, einops.rearrange, the normalize_feature expression on bf16 tensors)."""
+    print("[gen_golden] G11", flush=True)
+    from einops import rearrange
+    from safetensors.torch import load as sft_load, save as sft_save
+    C, H, W = 40, 6, 5
+    x = torch.from_numpy(O._hash_uniform(C * H * W, 91).reshape(C, H, W) * 5.0).to(torch.bfloat16)
+    mean = torch.from_numpy(O._hash_uniform(C, 92) * 0.5)
+    std = torch.from_numpy(np.abs(O._hash_uniform(C, 93)) * 2.0 + 0.25)
+    blob = sft_save({"embedding": x})
+    emb = rearrange(sft_load(blob)["embedding"], "c h w -> (h w) c")
+    y = ((emb - mean.to(torch.bfloat16)) / std.to(torch.bfloat16)).float()
+    np.savez_compressed(os.path.join(OUT, "g11_feature_ingest.npz"), blob=np.frombuffer(blob, dtype=np.uint8),
+                        x_bits=x.view(torch.int16).numpy(), mean=mean.numpy(), std=std.numpy(), y=y.numpy(),
+                        y_plain=emb.float().numpy())
+
+
 def gen_g10():
     """Per-op micro goldens straight from torch.nn (what the reference's modules call)."""
     print("[gen_golden] G10", flush=True)
@@ -347,6 +367,8 @@ def main():
         gen_g8()
     if want("g10"):
         gen_g10()
+    if want("g11"):
+        gen_g11()
     if want("g9"):
         gen_g9(RobotVisionFM, gmfs)
     print("[gen_golden] done")

@@ -524,6 +524,16 @@ def train_step_grads(params: Dict[str, torch.Tensor], images, targets: Dict[str,
 # ----------------------------------------------------------------------------------------
 # K14 / §8(f)-2: bf16 teacher-feature normalisation (dataset/data_utils.py:342-355,374-379)
 # ----------------------------------------------------------------------------------------
+def ingest_feature_chw_bf16(x_chw_bf16: torch.Tensor, mean_f32=None, std_f32=None) -> torch.Tensor:
+    """On-disk embedding [C,H,W] (or a batch [b,C,H,W]) bf16 -> tokens [(h w), C] (decode_sample's rearrange,
+    data_utils.py:152-155), normalised as below when statistics are given, widened to f32 (train_rvfm.py:112-114)."""
+    x = x_chw_bf16
+    tok = x.flatten(-2).transpose(-1, -2).contiguous()  # "c h w -> (h w) c"
+    if mean_f32 is None:
+        return tok.float()
+    return normalize_feature_bf16(tok, mean_f32, std_f32)
+
+
 def normalize_feature_bf16(x_bf16: torch.Tensor, mean_f32: torch.Tensor, std_f32: torch.Tensor) -> torch.Tensor:
     """x bf16 [HW,C]; stats are cast to bf16 (data_utils.py:374-379); (x-mean)/std in bf16 with a
     rounding after each op (data_utils.py:342-355); then .float() (train_rvfm.py:112-114)."""

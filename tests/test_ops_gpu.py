@@ -381,6 +381,29 @@ def test_token_select_modes_and_feature_norm(golden_dir):
     assert np.array_equal(y, g8["y"])  # two bf16 roundings reproduced bit-exactly
 
 
+@pytest.mark.parametrize("C,H", [(1280, 16), (1024, 16), (256, 64), (32, 64), (40, 7)])
+def test_feature_ingest_bit_exact(C, H):
+    """theia_feature_ingest_bf16 == decode_sample's rearrange + bf16 normalize_feature + .float() of the reference (oracle,
+    itself pinned by golden G8), bit for bit; also through FeatureIngest's pinned staging + safetensors decode."""
+    from safetensors.torch import save as sft_save
+    from theia_amd import ops
+    from theia_amd.dataset import FeatureIngest, decode_feature
+    dev = _dev()
+    b = 3
+    x = (h((b, C, H, H), 51) * 3.0).to(torch.bfloat16)
+    mean = h((C,), 52) * 0.5
+    std = h((C,), 53).abs() + 0.5
+    ref = O.ingest_feature_chw_bf16(x, mean, std)
+    got = ops.feature_ingest_bf16(x.to(dev), mean.to(dev), std.to(dev))
+    assert got.shape == (b, H * H, C) and torch.equal(got.cpu(), ref)
+    assert torch.equal(ops.feature_ingest_bf16(x.to(dev), None, None).cpu(), O.ingest_feature_chw_bf16(x))
+    ing = FeatureIngest(dev, {"t": mean}, {"t": std})
+    samples = [decode_feature(sft_save({"embedding": x[i]}))["embedding"] for i in range(b)]
+    for _ in range(2):  # second call reuses the pinned buffer
+        out = ing({"t": samples})["t"]
+        assert torch.equal(out.cpu(), ref)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_cast_batch_matches_single_casts(dt):
     """theia_cast_batch (one launch for the whole operand table) == the individual cast / transpose / permute kernels,

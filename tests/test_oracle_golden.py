@@ -104,6 +104,20 @@ def test_oracle_feature_norm_bf16_g8(golden_dir):
     assert np.array_equal(y, g["y"])
 
 
+def test_oracle_feature_ingest_g11(golden_dir):
+    """safetensors blob -> [C,H,W] bf16 -> (h w) c -> bf16 normalisation -> f32, against the reference's library calls."""
+    from theia_amd.dataset import decode_feature
+    g = np.load(os.path.join(golden_dir, "g11_feature_ingest.npz"))
+    x = torch.from_numpy(g["x_bits"]).view(torch.bfloat16)
+    dec = decode_feature(g["blob"].tobytes())["embedding"]
+    assert dec.dtype == torch.bfloat16 and torch.equal(dec, x)
+    y = O.ingest_feature_chw_bf16(dec, torch.from_numpy(g["mean"]), torch.from_numpy(g["std"])).numpy()
+    assert np.array_equal(y, g["y"])
+    assert np.array_equal(O.ingest_feature_chw_bf16(dec).numpy(), g["y_plain"])
+    yb = O.ingest_feature_chw_bf16(torch.stack([dec, dec]), torch.from_numpy(g["mean"]), torch.from_numpy(g["std"])).numpy()
+    assert yb.shape == (2,) + g["y"].shape and np.array_equal(yb[1], g["y"])
+
+
 def test_dp_equivalence_g9(golden_dir):
     """Reference DDP(gloo, 2 ranks x b=2) == single process b=4 (what data parallelism must preserve)."""
     g = np.load(os.path.join(golden_dir, "g9_dp2_vs_single.npz"))

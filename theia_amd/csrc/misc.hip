@@ -559,6 +559,47 @@ extern "C" int theia_feature_norm_bf16(const uint16_t* x, const float* mean, con
     return THEIA_OK;
 }
 
+// Teacher-feature ingest: the on-disk layout [C, H, W] bf16 -> tokens [(h w), C], normalised in bf16 with the
+// reference's two roundings, widened to f32 -- decode_sample's rearrange (data_utils.py:152-155) + normalize_feature
+// (:342-355, stats cast to bf16 :374-379) + .float() (train_rvfm.py:112-114) in one pass: 32 x 32 tile through LDS, reads
+// along the pixels, writes along the channels.  mean == nullptr: no normalisation.
+__global__ __launch_bounds__(256) void feature_ingest_kernel(const uint16_t* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ stdv, float* __restrict__ out, int C, int HW) {
+    __shared__ uint16_t tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const uint16_t* xb = x + (int64_t)blockIdx.z * C * HW;
+    float* ob = out + (int64_t)blockIdx.z * HW * C;
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, pp = p0 + tx;
+        if (c < C && pp < HW) tile[i][tx] = xb[(int64_t)c * HW + pp];
+    }
+    __syncthreads();
+    const int c = c0 + tx;
+    float m = 0.f, sd = 1.f;
+    if (mean != nullptr && c < C) {
+        m = bf16_to_f32(f32_to_bf16(mean[c]));
+        sd = bf16_to_f32(f32_to_bf16(stdv[c]));
+    }
+    for (int i = ty; i < 32; i += 8) {
+        const int pp = p0 + i;
+        if (c < C && pp < HW) {
+            float v = bf16_to_f32(tile[tx][i]);
+            if (mean != nullptr) v = bf16_to_f32(f32_to_bf16(bf16_to_f32(f32_to_bf16(v - m)) / sd));
+            ob[(int64_t)pp * C + c] = v;
+        }
+    }
+}
+extern "C" int theia_feature_ingest_bf16(const uint16_t* x_chw, const float* mean, const float* std, float* out, int b, int C, int HW,
+                                         void* stream) {
+    THEIA_CHECK_ARG(x_chw && out && b > 0 && C > 0 && HW > 0 && b < 65536, "theia_feature_ingest_bf16: bad args");
+    THEIA_CHECK_ARG((mean == nullptr) == (std == nullptr), "theia_feature_ingest_bf16: mean and std go together");
+    const dim3 grid((HW + 31) / 32, (C + 31) / 32, b);
+    hipLaunchKernelGGL(feature_ingest_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x_chw, mean, std, out, C, HW);
+    THEIA_CHECK_LAUNCH("theia_feature_ingest_bf16");
+    return THEIA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // elementwise helpers
 // ------------------------------------------------------------------------------------------------

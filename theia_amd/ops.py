@@ -431,6 +431,20 @@ def token_select(x: torch.Tensor, b: int, n: int, D: int, disc: int, mode: int) 
     return out
 
 
+def feature_ingest_bf16(x_chw: torch.Tensor, mean: Optional[torch.Tensor], std: Optional[torch.Tensor],
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x_chw [b, C, H, W] (or [b, C, HW]) bf16 as stored on disk -> [b, HW, C] f32, normalised with the reference's bf16
+    arithmetic when mean/std (f32 [C]) are given."""
+    assert x_chw.dtype == torch.bfloat16 and x_chw.is_cuda and x_chw.is_contiguous() and x_chw.dim() in (3, 4)
+    b, Cc = x_chw.shape[0], x_chw.shape[1]
+    HW = x_chw.numel() // (b * Cc)
+    if out is None:
+        out = torch.empty(b, HW, Cc, dtype=torch.float32, device=x_chw.device)
+    N.check(N.lib().theia_feature_ingest_bf16(x_chw.data_ptr(), N.ptr(mean), N.ptr(std), out.data_ptr(), b, Cc, HW, N.stream_ptr()),
+            "theia_feature_ingest_bf16")
+    return out
+
+
 def feature_norm_bf16(x_bf16: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> torch.Tensor:
     rows, Cc = x_bf16.shape
     out = torch.empty(rows, Cc, dtype=torch.float32, device=x_bf16.device)

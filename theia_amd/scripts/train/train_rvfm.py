@@ -41,10 +41,20 @@ class SyntheticFrames:
     """Infinite iterator of synthetic batches in the reference's batch format
     ({"image": uint8 [b,224,224,3], teacher: {"embedding": [b, HW, C]}}), generated on the device."""
 
-    def __init__(self, batch_size: int, target_model_names, device, seed: int, fixed: bool = False):
+    def __init__(self, batch_size: int, target_model_names, device, seed: int, fixed: bool = False, on_disk_format: bool = False):
         self.b, self.names, self.device = batch_size, list(target_model_names), device
         self.gen = torch.Generator(device=device).manual_seed(seed)
         self.fixed, self._cached = fixed, None  # fixed: replay one batch (over-fitting sanity runs)
+        # on_disk_format: synthesise the features as the extractor stores them (bf16 [C, H, W] per sample, host memory, with
+        # per-channel statistics) and run them through the real ingest path (pinned staging -> H2D -> theia_feature_ingest_bf16)
+        self.ingest = None
+        if on_disk_format:
+            from theia_amd.dataset import FeatureIngest
+            cpu_gen = torch.Generator().manual_seed(seed + 1)
+            means = {t: torch.randn(get_model_feature_size(t, keep_spatial=True)[0], generator=cpu_gen) * 0.1 for t in self.names}
+            stds = {t: torch.rand(get_model_feature_size(t, keep_spatial=True)[0], generator=cpu_gen) + 0.5 for t in self.names}
+            self.ingest = FeatureIngest(device, means, stds)
+            self.cpu_gen = cpu_gen
 
     def __iter__(self) -> Iterator[dict]:
         return self
@@ -54,9 +64,15 @@ class SyntheticFrames:
             return self._cached
         batch: dict[str, Any] = {"image": torch.randint(0, 256, (self.b, 224, 224, 3), dtype=torch.uint8, device=self.device,
                                                         generator=self.gen)}
-        for t in self.names:
-            C, H, W = get_model_feature_size(t, keep_spatial=True)
-            batch[t] = {"embedding": torch.randn(self.b, H * W, C, device=self.device, generator=self.gen)}
+        if self.ingest is not None:
+            raw = {t: torch.randn((self.b,) + tuple(get_model_feature_size(t, keep_spatial=True)), generator=self.cpu_gen).to(torch.bfloat16)
+                   for t in self.names}
+            for t, emb in self.ingest(raw).items():
+                batch[t] = {"embedding": emb}
+        else:
+            for t in self.names:
+                C, H, W = get_model_feature_size(t, keep_spatial=True)
+                batch[t] = {"embedding": torch.randn(self.b, H * W, C, device=self.device, generator=self.gen)}
         self._cached = batch if self.fixed else None
         return batch
 
@@ -174,8 +190,9 @@ def ddp_main(cfg) -> dict:
     train_epoch_steps = int(cfg.dataset.get("train_steps_per_epoch", 20))
     eval_epoch_steps = int(cfg.dataset.get("eval_steps_per_epoch", 2))
     fixed = bool(cfg.dataset.get("fixed_batch", False))
-    train_iter = SyntheticFrames(cfg.training.batch_size, target_model_names, device, cfg.seed + rank * 100, fixed)
-    eval_iter = SyntheticFrames(cfg.training.batch_size, target_model_names, device, cfg.seed + (rank * 100 if fixed else 7777), fixed)
+    on_disk = bool(cfg.dataset.get("feature_norm", False))  # dataset.feature_norm=true: features arrive as stored + statistics
+    train_iter = SyntheticFrames(cfg.training.batch_size, target_model_names, device, cfg.seed + rank * 100, fixed, on_disk)
+    eval_iter = SyntheticFrames(cfg.training.batch_size, target_model_names, device, cfg.seed + (rank * 100 if fixed else 7777), fixed, on_disk)
     total_train_steps = train_epoch_steps * cfg.training.epochs
 
     lr = cfg.training.base_lr * ((cfg.training.batch_size * world_size) / (cfg.training.base_batch_size * cfg.training.base_world_size))
