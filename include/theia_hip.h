@@ -181,6 +181,15 @@ int theia_cast_batch(const theia_cast_job_t* jobs_device, int njobs, int64_t tot
 int theia_unpermute3_f32(const float* src, float* dst, int d0, int d1, int d2, int64_t t0, int64_t t1,
                          int64_t t2, int accumulate, void* stream);
 
+/* Image resize of the reference's HF image processor (models/backbones.py:337-339 -> Pillow Image.resize, two-pass 8-bit
+ * resampling, Pillow 12.2.0 src/libImaging/Resample.c): src uint8 [b, in_h, in_w, 3] (channels_last) or [b, 3, in_h, in_w]
+ * -> dst uint8 [b, out_h, out_w, 3].  The filter weights are host-computed 22-bit fixed-point tables (bounds: (first source
+ * index, tap count) per output index; weights: [out][ksize]); the vertical tables are relative to first_row when a
+ * horizontal pass runs (in_w != out_w), which covers source rows [first_row, first_row + tmp_rows) into tmp
+ * (b*tmp_rows*out_w*3 bytes).  Bit-exact integer arithmetic. */
+int theia_resize_u8(const uint8_t* src, uint8_t* dst, uint8_t* tmp, int b, int in_h, int in_w, int channels_last, int out_h,
+                    int out_w, const int32_t* bounds_x, const int32_t* weights_x, int ksize_x, const int32_t* bounds_y,
+                    const int32_t* weights_y, int ksize_y, int first_row, int tmp_rows, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * K1: image ingest.  uint8 [b,224,224,3] (channels_last=1) or [b,3,224,224] (0) -> patch matrix
  * [b*196, 768] with K index c*256 + ky*16 + kx, through a [3][256] f32 look-up table that reproduces the

@@ -210,6 +210,40 @@ def gen_g6_g7(RobotVisionFM, gmfs, hfo):
     np.savez_compressed(os.path.join(OUT, "g6_g7_tokens_layouts.npz"), **fx)
 
 
+def gen_g12(RobotVisionFM, gmfs):
+    """Non-224 inputs through the REFERENCE model's own processor and backbone (backbones.py:337-339, do_resize=True):
+    the resized uint8 image the processor produces (do_rescale=False, do_normalize=False returns it), the full pixel_values,
+    and forward_feature of the reference on those inputs."""
+    print("[gen_golden] G12", flush=True)
+    backbone = "facebook/deit-tiny-patch16-224"
+    teachers = O.TEACHER_SETS["dinov2"]
+    model, params = build_reference(RobotVisionFM, gmfs, backbone, teachers)
+    model.eval()
+    proc = model.backbone.processor
+    fx = {}
+    rows = np.arange(0, 224, 7)
+    cases = {"up_hwc": (2, 50, 37, True), "down_chw": (1, 150, 131, False), "xonly_hwc": (1, 224, 120, True), "yonly_chw": (1, 90, 224, False)}
+    for name, (b, hh, ww, cl) in cases.items():
+        img = torch.from_numpy((O._hash_uniform(b * hh * ww * 3, 300 + hh) * 0.5 + 0.5).reshape(b, hh, ww, 3) * 255.999).to(torch.uint8)
+        x = img if cl else img.permute(0, 3, 1, 2).contiguous()
+        fx[f"{name}_img"] = x.numpy()
+        with torch.no_grad():
+            raw = proc(x, return_tensors="pt", do_resize=True, do_rescale=False, do_normalize=False)["pixel_values"]  # [b,3,224,224]
+            pv = proc(x, return_tensors="pt", do_resize=True)["pixel_values"]
+            z = model.forward_feature(x)
+        r8 = raw.permute(0, 2, 3, 1).round().to(torch.uint8).numpy()  # HWC
+        assert np.array_equal(r8.astype(np.float32), raw.permute(0, 2, 3, 1).numpy())
+        fx[f"{name}_resized_rows"] = r8[:, rows]
+        fx[f"{name}_resized_sum"] = np.array(r8.astype(np.int64).sum())
+        fx[f"{name}_pv_rows"] = pv.permute(0, 2, 3, 1).numpy()[:, rows[::4]]
+        zi = sample_idx(z.numel(), 64, 13)
+        fx[f"{name}_z_idx"] = zi
+        fx[f"{name}_z_val"] = z.numpy().reshape(-1)[zi]
+        fx[f"{name}_z_abssum"] = np.array(np.abs(z.numpy().astype(np.float64)).sum())
+    fx["rows"] = rows
+    np.savez_compressed(os.path.join(OUT, "g12_resize_processor.npz"), **fx)
+
+
 def gen_g8():
     print("[gen_golden] G8", flush=True)
     sys.path.insert(0, REF_SRC)
@@ -365,6 +399,8 @@ def main():
         gen_g6_g7(RobotVisionFM, gmfs, hfo)
     if want("g8"):
         gen_g8()
+    if want("g12"):
+        gen_g12(RobotVisionFM, gmfs)
     if want("g10"):
         gen_g10()
     if want("g11"):

@@ -168,6 +168,31 @@ def test_input_layouts_and_reduce_modes(golden_dir):
             model.forward_feature(images)
 
 
+def test_non_224_inputs_go_through_the_processor_resize(golden_dir):
+    """forward_feature on non-224 images (do_resize=True): against the REFERENCE's forward_feature on the same inputs (golden
+    G12: its processor resizes with Pillow), for both layouts, single-pass cases and a list of differently sized images."""
+    from PIL import Image
+    g = np.load(os.path.join(golden_dir, "g12_resize_processor.npz"))
+    bb, teachers = "facebook/deit-tiny-patch16-224", O.TEACHER_SETS["dinov2"]
+    m, _ = build(bb, teachers, "fp32")
+    for name in ("up_hwc", "down_chw", "xonly_hwc", "yonly_chw"):
+        x = torch.from_numpy(g[f"{name}_img"])
+        with torch.no_grad():
+            z = m.forward_feature(x).float().cpu().numpy()
+        assert rel(np.abs(z.astype(np.float64)).sum(), float(g[f"{name}_z_abssum"])) < 1e-4, name
+        assert np.allclose(z.reshape(-1)[g[f"{name}_z_idx"]], g[f"{name}_z_val"], rtol=1e-3, atol=2e-4), name
+    # a list of PIL images of different sizes == each image on its own
+    a = g["up_hwc_img"][0]
+    b_ = np.transpose(g["down_chw_img"][0], (1, 2, 0))
+    with torch.no_grad():
+        zl = m.forward_feature([Image.fromarray(a), Image.fromarray(np.ascontiguousarray(b_))])
+        z0 = m.forward_feature(torch.from_numpy(a[None]))
+        z1 = m.forward_feature(torch.from_numpy(g["down_chw_img"]))
+    assert torch.equal(zl[0], z0[0]) and torch.equal(zl[1], z1[0])
+    with pytest.raises(NotImplementedError):
+        m.forward_feature(torch.from_numpy(a[None]), do_resize=False)
+
+
 def test_grad_accumulation_and_freeze_translator():
     bb, teachers = "facebook/deit-tiny-patch16-224", O.TEACHER_SETS["dinov2"]
     model, _ = build(bb, teachers, "fp32")

@@ -381,6 +381,24 @@ def test_token_select_modes_and_feature_norm(golden_dir):
     assert np.array_equal(y, g8["y"])  # two bf16 roundings reproduced bit-exactly
 
 
+@pytest.mark.parametrize("resample", [2, 3])
+@pytest.mark.parametrize("hh,ww", [(50, 37), (300, 200), (224, 301), (301, 224), (448, 448), (17, 400), (1000, 750)])
+def test_resize_u8_bit_exact(hh, ww, resample):
+    """theia_resize_u8 == Pillow's Image.resize as the reference's processor calls it (oracle/pil_resize.py, pinned against
+    Pillow and golden G12), bit for bit, both input layouts, both passes / single passes."""
+    from oracle import pil_resize as R
+    from theia_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(hh * 1000 + ww)
+    img = rng.integers(0, 256, (2, hh, ww, 3), dtype=np.uint8)
+    ref = np.stack([R.resize_u8(im, 224, 224, resample) for im in img])
+    t = torch.from_numpy(img)
+    got = ops.resize_u8(t.to(dev), True, 224, 224, resample)
+    assert got.shape == (2, 224, 224, 3) and np.array_equal(got.cpu().numpy(), ref)
+    got = ops.resize_u8(t.permute(0, 3, 1, 2).contiguous().to(dev), False, 224, 224, resample)
+    assert np.array_equal(got.cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("C,H", [(1280, 16), (1024, 16), (256, 64), (32, 64), (40, 7)])
 def test_feature_ingest_bit_exact(C, H):
     """theia_feature_ingest_bf16 == decode_sample's rearrange + bf16 normalize_feature + .float() of the reference (oracle,

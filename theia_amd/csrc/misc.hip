@@ -213,6 +213,79 @@ extern "C" int theia_unpermute3_f32(const float* src, float* dst, int d0, int d1
 }
 
 // ------------------------------------------------------------------------------------------------
+// Image resize of the HF processor: Pillow's two-pass 8-bit resampling, integer arithmetic only.
+// The double-precision filter weights are computed on the host (theia_amd/preprocess.py) and arrive as 22-bit fixed-point
+// tables; a pass is  out = clip8((2^21 + sum_t src[first + t] * w[t]) >> 22)  per channel (Pillow 12.2.0
+// src/libImaging/Resample.c ImagingResampleHorizontal_8bpc / Vertical_8bpc), horizontal pass first into a uint8 image.
+// Source addressed by byte strides (channels-last or channels-first input), destination [b][lines][pos][3].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_pass_kernel(const uint8_t* __restrict__ src, int64_t s_b, int64_t s_line, int64_t s_tap,
+                                                          int64_t s_c, uint8_t* __restrict__ dst, const int32_t* __restrict__ bounds,
+                                                          const int32_t* __restrict__ weights, int ksize, int lines, int outn,
+                                                          int along_pos) {
+    // along_pos = 1 (horizontal pass): output (line = y, pos = xx), taps walk the source x;  s_line = row stride
+    // along_pos = 0 (vertical pass):   output (line = yy, pos = x), taps walk the source y;  s_line = column stride
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t per = (int64_t)lines * outn;
+    if (i >= per) return;
+    const int b = blockIdx.y;
+    const int line = (int)(i / outn), pos = (int)(i - (int64_t)line * outn);
+    const int o = along_pos ? pos : line;           // index into the coefficient tables
+    const int fixed = along_pos ? line : pos;       // coordinate that is copied through
+    const int first = bounds[2 * o], n = bounds[2 * o + 1];
+    const int32_t* __restrict__ k = weights + (int64_t)o * ksize;
+    const uint8_t* __restrict__ p = src + b * s_b + fixed * s_line + first * s_tap;
+    int32_t a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+    for (int t = 0; t < n; ++t) {
+        const int32_t w = k[t];
+        a0 += (int32_t)p[0] * w;
+        a1 += (int32_t)p[s_c] * w;
+        a2 += (int32_t)p[2 * s_c] * w;
+        p += s_tap;
+    }
+    uint8_t* q = dst + (((int64_t)b * lines + line) * outn + pos) * 3;
+    q[0] = (uint8_t)min(max(a0 >> 22, 0), 255);
+    q[1] = (uint8_t)min(max(a1 >> 22, 0), 255);
+    q[2] = (uint8_t)min(max(a2 >> 22, 0), 255);
+}
+extern "C" int theia_resize_u8(const uint8_t* src, uint8_t* dst, uint8_t* tmp, int b, int in_h, int in_w, int channels_last, int out_h,
+                               int out_w, const int32_t* bounds_x, const int32_t* weights_x, int ksize_x, const int32_t* bounds_y,
+                               const int32_t* weights_y, int ksize_y, int first_row, int tmp_rows, void* stream) {
+    THEIA_CHECK_ARG(src && dst && b > 0 && b < 65536 && in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0, "theia_resize_u8: bad shape");
+    THEIA_CHECK_ARG(in_w == out_w || (bounds_x && weights_x && ksize_x > 0), "theia_resize_u8: the horizontal pass needs its tables");
+    THEIA_CHECK_ARG(in_w == out_w || in_h == out_h || (tmp && tmp_rows > 0 && first_row >= 0 && first_row + tmp_rows <= in_h),
+                    "theia_resize_u8: two passes need tmp and the source row range of the vertical pass");
+    THEIA_CHECK_ARG(in_h == out_h || (bounds_y && weights_y && ksize_y > 0), "theia_resize_u8: the vertical pass needs its tables");
+    THEIA_CHECK_ARG(in_w != out_w || in_h != out_h, "theia_resize_u8: nothing to do (same size)");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // source strides in bytes: [b, H, W, 3] or [b, 3, H, W]
+    int64_t sb = (int64_t)in_h * in_w * 3, sy = channels_last ? (int64_t)in_w * 3 : in_w, sx = channels_last ? 3 : 1,
+            sc = channels_last ? 1 : (int64_t)in_h * in_w;
+    const uint8_t* cur = src;
+    int cur_h = in_h;
+    if (in_w != out_w) {  // horizontal pass over the rows the vertical pass reads: tmp [b][rows][out_w][3]
+        const bool last = in_h == out_h;
+        const int rows = last ? in_h : tmp_rows, row0 = last ? 0 : first_row;
+        uint8_t* out = last ? dst : tmp;
+        const int64_t per = (int64_t)rows * out_w;
+        hipLaunchKernelGGL(resize_pass_kernel, dim3((unsigned)((per + 255) / 256), b), dim3(256), 0, s, cur + row0 * sy, sb, sy, sx, sc, out,
+                           bounds_x, weights_x, ksize_x, rows, out_w, 1);
+        THEIA_CHECK_LAUNCH("theia_resize_u8(horizontal)");
+        if (last) return THEIA_OK;
+        cur = tmp;
+        cur_h = rows;
+        sb = (int64_t)rows * out_w * 3; sy = (int64_t)out_w * 3; sx = 3; sc = 1;
+    }
+    // vertical pass (tables already shifted by first_row when a horizontal pass ran): lines = out_h, pos = x, taps walk y
+    (void)cur_h;
+    const int64_t per = (int64_t)out_h * out_w;
+    hipLaunchKernelGGL(resize_pass_kernel, dim3((unsigned)((per + 255) / 256), b), dim3(256), 0, s, cur, sb, sx, sy, sc, dst, bounds_y,
+                       weights_y, ksize_y, out_h, out_w, 0);
+    THEIA_CHECK_LAUNCH("theia_resize_u8(vertical)");
+    return THEIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1: uint8 image -> normalised patch matrix.  One thread produces 8 consecutive kx of one (patch, c, ky).
 // Token/patch indexing is integer-exact: row = b*196 + py*14 + px, col = c*256 + ky*16 + kx.
 // ------------------------------------------------------------------------------------------------

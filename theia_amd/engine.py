@@ -50,14 +50,18 @@ def preprocess_lut(do_rescale: bool, do_normalize: bool, mean: Sequence[float], 
     return lut
 
 
-def to_uint8_batch(x: Any) -> Tuple[torch.Tensor, bool]:
+def to_uint8_batch(x: Any, any_size: bool = False):
     """Accepts what the reference's DeiT.forward accepts (uint8 torch [B,H,W,C] / [B,C,H,W], single image, numpy,
-    list of PIL images / arrays).  Returns (uint8 tensor, channels_last).  Channel layout inference follows
-    transformers image_utils.infer_channel_dimension_format: a leading dim of 1/3 means channels-first."""
+    list of PIL images / arrays).  Returns (uint8 tensor, channels_last) -- or, for a list whose items differ in size (only
+    with any_size), a list of such pairs.  Channel layout inference follows transformers
+    image_utils.infer_channel_dimension_format: a leading dim of 1/3 means channels-first.
+    any_size=False: only 224x224 images (what the patch-embedding consumes); True: the caller resizes."""
     if isinstance(x, (list, tuple)):
-        items = [to_uint8_batch(i) for i in x]
+        items = [to_uint8_batch(i, any_size) for i in x]
         cl = items[0][1]
         ts = [t if c == cl else (t.permute(0, 2, 3, 1) if cl else t.permute(0, 3, 1, 2)) for t, c in items]
+        if len({tuple(t.shape[1:]) for t in ts}) > 1:
+            return [(t.contiguous(), cl) for t in ts]
         return torch.cat(ts, 0).contiguous(), cl
     if not isinstance(x, (torch.Tensor, np.ndarray)):
         x = np.asarray(x)  # PIL
@@ -75,9 +79,9 @@ def to_uint8_batch(x: Any) -> Tuple[torch.Tensor, bool]:
     if (channels_last and x.shape[-1] != 3) or (not channels_last and x.shape[1] != 3):
         raise ValueError(f"expected 3-channel images, got shape {tuple(x.shape)}")
     hh, ww = (x.shape[1], x.shape[2]) if channels_last else (x.shape[2], x.shape[3])
-    if hh != IMAGE or ww != IMAGE:
-        raise NotImplementedError(f"{hh}x{ww} input: resize / crop / pos-emb interpolation are outside the hot path "
-                                  f"(SURVEY.md sec. 8f-3); feed {IMAGE}x{IMAGE} images")
+    if not any_size and (hh != IMAGE or ww != IMAGE):
+        raise NotImplementedError(f"{hh}x{ww} input with do_resize=False: position-embedding interpolation is outside the hot "
+                                  f"path (SURVEY.md sec. 8f-3); feed {IMAGE}x{IMAGE} images or keep do_resize=True")
     return x.contiguous(), channels_last
 
 
@@ -364,18 +368,40 @@ class StudentEngine:
         return oc, cb
 
     # ================================================================== backbone
-    def backbone(self, x: Any, do_rescale: bool = True, do_normalize: bool = True) -> torch.Tensor:
+    def backbone(self, x: Any, do_rescale: bool = True, do_normalize: bool = True, do_resize: bool = True) -> torch.Tensor:
         vit = self.rvfm.backbone.model
         device = vit.layernorm.weight.device
         if device.type != "cuda":
             raise RuntimeError("theia_amd runs on a ROCm GPU only: move the model with .to('cuda') (no CPU fallback)")
-        img, channels_last = to_uint8_batch(x)
-        img = img.to(device, non_blocking=True)
+        batch = to_uint8_batch(x, any_size=do_resize)
+        img, channels_last = self._to_model_size(batch, device)
         params = list(vit.parameters())
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _BackboneFn.apply(self, img, channels_last, do_rescale, do_normalize, *params)
         z, _ = self._backbone_fwd(img, channels_last, do_rescale, do_normalize, save=False)
         return z
+
+    def _to_model_size(self, batch, device) -> Tuple[torch.Tensor, bool]:
+        """The processor's resize step (backbones.py:337-339 with do_resize=True): anything that is not 224x224 goes through
+        theia_resize_u8 (Pillow's resampling, bit-exact) on the GPU; 224x224 input passes through untouched."""
+        resample = int(getattr(self.rvfm.backbone, "resample", 2))
+        if isinstance(batch, list):  # items of different sizes: one resize launch per item, then one batch
+            outs = []
+            for t, cl in batch:
+                t = t.to(device, non_blocking=True)
+                hh, ww = (t.shape[1], t.shape[2]) if cl else (t.shape[2], t.shape[3])
+                if (hh, ww) != (IMAGE, IMAGE):
+                    t = ops.resize_u8(t, cl, IMAGE, IMAGE, resample)
+                elif not cl:
+                    t = t.permute(0, 2, 3, 1).contiguous()
+                outs.append(t)
+            return torch.cat(outs, 0).contiguous(), True
+        img, channels_last = batch
+        img = img.to(device, non_blocking=True)
+        hh, ww = (img.shape[1], img.shape[2]) if channels_last else (img.shape[2], img.shape[3])
+        if (hh, ww) != (IMAGE, IMAGE):
+            return ops.resize_u8(img, channels_last, IMAGE, IMAGE, resample), True
+        return img, channels_last
 
     def _backbone_fwd(self, img: torch.Tensor, channels_last: bool, do_rescale: bool, do_normalize: bool, save: bool):
         dev, T, D, F, nh = img.device, self.dtype, self.D, self.F, self.heads

@@ -152,6 +152,7 @@ class DeiT(nn.Module):
         # explicit processor configuration: 224, no crop, ImageNet mean/std
         self.image_mean = (0.485, 0.456, 0.406)
         self.image_std = (0.229, 0.224, 0.225)
+        self.resample = 2  # PIL BILINEAR (ViTImageProcessor default); 3 = BICUBIC (DeiTImageProcessor class default)
         self._engine = None  # set by RobotVisionFM
 
     def get_feature_size(self, keep_spatial: bool = False, return_torch_size: bool = False):
@@ -170,7 +171,7 @@ class DeiT(nn.Module):
             raise RuntimeError("DeiT is driven by RobotVisionFM's engine; construct it through RobotVisionFM")
         if interpolate_pos_encoding:
             raise NotImplementedError("interpolate_pos_encoding is outside the round-1 hot path (SURVEY.md sec. 8f-3)")
-        return self._engine.backbone(x, do_rescale=do_rescale, do_normalize=do_normalize)
+        return self._engine.backbone(x, do_rescale=do_rescale, do_normalize=do_normalize, do_resize=do_resize)
 
 
 def build_backbone(model_name: str, pretrained: bool = False, image_size: int = 224, **kwargs: Any) -> nn.Module:

@@ -325,6 +325,21 @@ def unpermute3(src: torch.Tensor, dst: torch.Tensor, d0: int, d1: int, d2: int, 
                                          N.stream_ptr()), "theia_unpermute3_f32")
 
 
+def resize_u8(img: torch.Tensor, channels_last: bool, out_h: int, out_w: int, resample: int = 2) -> torch.Tensor:
+    """uint8 [b,H,W,3] / [b,3,H,W] on the GPU -> uint8 [b,out_h,out_w,3]: Image.resize((out_w, out_h), resample) of Pillow."""
+    from .preprocess import resize_plan
+    assert img.dtype == torch.uint8 and img.is_cuda and img.is_contiguous() and img.dim() == 4
+    b = img.shape[0]
+    in_h, in_w = (img.shape[1], img.shape[2]) if channels_last else (img.shape[2], img.shape[3])
+    pl = resize_plan(in_h, in_w, out_h, out_w, resample, img.device)
+    out = torch.empty(b, out_h, out_w, 3, dtype=torch.uint8, device=img.device)
+    tmp = torch.empty(b * pl.tmp_rows * out_w * 3, dtype=torch.uint8, device=img.device) if in_w != out_w and in_h != out_h else None
+    N.check(N.lib().theia_resize_u8(img.data_ptr(), out.data_ptr(), N.ptr(tmp), b, in_h, in_w, int(channels_last), out_h, out_w,
+                                    pl.bx.data_ptr(), pl.kx.data_ptr(), pl.ksize_x, pl.by.data_ptr(), pl.ky.data_ptr(), pl.ksize_y,
+                                    pl.first_row, pl.tmp_rows, N.stream_ptr()), "theia_resize_u8")
+    return out
+
+
 def patchify(img: torch.Tensor, lut: torch.Tensor, out: torch.Tensor, channels_last: bool) -> None:
     b = img.shape[0]
     N.check(N.lib().theia_patchify_u8(img.data_ptr(), lut.data_ptr(), out.data_ptr(), b, int(channels_last), _dt(out),
