@@ -76,7 +76,9 @@ def build_reference(RobotVisionFM, get_model_feature_size, backbone, teachers, s
     m = RobotVisionFM(
         backbone=backbone, pretrained=False, translator="lconv",
         translator_kwargs={"hidden_size_factor": 1.0},
-        target_feature_sizes={t: get_model_feature_size(t, keep_spatial=True) for t in teachers},
+        # "<teacher>_cls" heads as scripts/train/train_rvfm.py:238-246 sizes them
+        target_feature_sizes={t: (get_model_feature_size(t[:-4], keep_spatial=True)[:1] if t.endswith("_cls")
+                                  else get_model_feature_size(t, keep_spatial=True)) for t in teachers},
     )
     params = O.synth_params(backbone, teachers, seed)
     sd = m.state_dict()
@@ -395,6 +397,9 @@ def main():
     if want("g5"):
         run_case("g5_base_cddsv_b1", "facebook/deit-base-patch16-224", T["cddsv"], 1, RobotVisionFM, gmfs,
                  loss_kinds=("cos_l1",))
+    if want("g13"):  # CLS-token distillation heads (train_rvfm.py distill_cls): a spatial head + two "_cls" heads
+        run_case("g13_tiny_dinov2_cls_b2", "facebook/deit-tiny-patch16-224",
+                 ["facebook/dinov2-large", "facebook/dinov2-large_cls", "openai/clip-vit-large-patch14_cls"], 2, RobotVisionFM, gmfs)
     if want("g6"):
         gen_g6_g7(RobotVisionFM, gmfs, hfo)
     if want("g8"):

@@ -134,8 +134,13 @@ def param_shapes(backbone: str, teachers: Sequence[str]) -> "Dict[str, Tuple[int
     shapes["backbone.model.layernorm.bias"] = (D,)
     C = D  # hidden_size_factor = 1.0 (configs/model/translator/lconv.yaml)
     for t in teachers:
-        Ct, Ht, _Wt = MODEL_FEATURE_SIZES[t]
         p = f"translator.translator_heads.{head_key(t)}."
+        if t.endswith("_cls"):  # LinearAdapterHead on token 0 (adapter_heads.py:28-58; names from train_rvfm.py:238-246)
+            Ct = MODEL_FEATURE_SIZES[t[:-4]][0]
+            shapes[p + "adapter.0.weight"] = (Ct, C)
+            shapes[p + "adapter.0.bias"] = (Ct,)
+            continue
+        Ct, Ht, _Wt = MODEL_FEATURE_SIZES[t]
         shapes[p + "pad.1.weight"] = (C, C, 3, 3)
         shapes[p + "pad.1.bias"] = (C,)
         if Ht == 16:
@@ -169,7 +174,7 @@ def synth_params(backbone: str, teachers: Sequence[str], seed: int = 0) -> "Dict
         n = int(np.prod(shape))
         u = _hash_uniform(n, seed * 100003 + idx + 1)
         leaf = name.rsplit(".", 1)[-1]
-        is_ln = ("layernorm" in name) or any(f"adapter.{k}." in name for k in (0, 3, 6))
+        is_ln = ("layernorm" in name) or (any(f"adapter.{k}." in name for k in (0, 3, 6)) and len(shape) == 3)
         if is_ln and leaf == "weight":
             v = 1.0 + 0.1 * u
         elif is_ln and leaf == "bias":
@@ -194,7 +199,7 @@ def synth_params(backbone: str, teachers: Sequence[str], seed: int = 0) -> "Dict
 
 def _is_convT(name: str, shape, teachers) -> bool:
     for t in teachers:
-        if head_key(t) in name and MODEL_FEATURE_SIZES[t][1] == 64:
+        if not t.endswith("_cls") and head_key(t) + "." in name and MODEL_FEATURE_SIZES[t][1] == 64:
             return True
     return False
 
@@ -210,6 +215,11 @@ def synth_targets(b: int, teachers: Sequence[str], seed: int = 1) -> "Dict[str, 
     """fp32 teacher features [b, H*W, Ct], roughly unit variance, from the integer hash."""
     out = {}
     for i, t in enumerate(teachers):
+        if t.endswith("_cls"):  # the teacher's CLS token: [b, Ct]
+            Ct = MODEL_FEATURE_SIZES[t[:-4]][0]
+            u = _hash_uniform(b * Ct, 104729 * (seed + 1) + i)
+            out[t] = torch.from_numpy((u * math.sqrt(3.0)).reshape(b, Ct).astype(np.float32))
+            continue
         Ct, Ht, Wt = MODEL_FEATURE_SIZES[t]
         n = b * Ht * Wt * Ct
         u = _hash_uniform(n, 104729 * (seed + 1) + i)
@@ -419,9 +429,12 @@ def layernorm_chw(x: torch.Tensor, w_chw: torch.Tensor, b_chw: torch.Tensor, eps
 
 
 def head_forward(params: Dict[str, torch.Tensor], z: torch.Tensor, teacher: str) -> torch.Tensor:
-    """z [b,197,C] (final LN output incl. CLS) -> predicted teacher feature [b, Ht*Wt, Ct]."""
-    Ct, Ht, Wt = MODEL_FEATURE_SIZES[teacher]
+    """z [b,197,C] (final LN output incl. CLS) -> predicted teacher feature [b, Ht*Wt, Ct] (or [b, Ct] for a "_cls" head:
+    one Linear on token 0, adapter_heads.py:50-57)."""
     p = f"translator.translator_heads.{head_key(teacher)}."
+    if teacher.endswith("_cls"):
+        return z[:, 0] @ params[p + "adapter.0.weight"].t() + params[p + "adapter.0.bias"]
+    Ct, Ht, Wt = MODEL_FEATURE_SIZES[teacher]
     b, _n, C = z.shape
     x = z[:, 1:, :].reshape(b, GRID, GRID, C)  # adapter_heads.py:355-356 + Rearrange :281
     # pad: ConvTranspose2d(C,C,3,stride=1,output_padding=0): 14 -> 16 (adapter_heads.py:279-290)

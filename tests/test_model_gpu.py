@@ -21,6 +21,7 @@ CASES = {
     "g3": "g3_tiny_cddsv_b2.npz",
     "g4": "g4_small_cddsv_b1.npz",
     "g5": "g5_base_cddsv_b1.npz",
+    "g13": "g13_tiny_dinov2_cls_b2.npz",  # a spatial head + two CLS-token heads (distill_cls)
 }
 
 
@@ -28,7 +29,8 @@ def build(backbone, teachers, precision, seed=0):
     from theia_amd.models.rvfm import RobotVisionFM
     from theia_amd.foundation_models.common import get_model_feature_size
     m = RobotVisionFM(backbone=backbone, translator="lconv", translator_kwargs={"hidden_size_factor": 1.0},
-                      target_feature_sizes={t: get_model_feature_size(t, keep_spatial=True) for t in teachers},
+                      target_feature_sizes={t: (get_model_feature_size(t[:-4], keep_spatial=True)[:1] if t.endswith("_cls")
+                                                else get_model_feature_size(t, keep_spatial=True)) for t in teachers},
                       precision=precision)
     params = O.synth_params(backbone, teachers, seed)
     missing, unexpected = m.load_state_dict(params, strict=True), None
@@ -44,7 +46,7 @@ def rel(a, b):
     return abs(a - b) / (abs(b) + 1e-30)
 
 
-@pytest.mark.parametrize("key", ["g1", "g2", "g3", "g4", "g5"])
+@pytest.mark.parametrize("key", ["g1", "g2", "g3", "g4", "g5", "g13"])
 def test_fp32_matches_reference_goldens(golden_dir, key):
     g, bb, teachers, B = load_case(golden_dir, key)
     model, _ = build(bb, teachers, "fp32")

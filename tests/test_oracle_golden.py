@@ -16,7 +16,7 @@ def rel(a, b):
     return abs(a - b) / (abs(b) + 1e-30)
 
 
-@pytest.mark.parametrize("name", ["g1_tiny_dinov2_b8", "g2_tiny_cdiv_b2", "g3_tiny_cddsv_b2", "g4_small_cddsv_b1"])
+@pytest.mark.parametrize("name", ["g1_tiny_dinov2_b8", "g2_tiny_cdiv_b2", "g3_tiny_cddsv_b2", "g4_small_cddsv_b1", "g13_tiny_dinov2_cls_b2"])
 def test_oracle_matches_reference_goldens(golden_dir, name):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     bb, teachers, B = str(g["meta_backbone"]), [str(t) for t in g["meta_teachers"]], int(g["meta_B"])

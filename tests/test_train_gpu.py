@@ -34,6 +34,19 @@ def test_train_script_with_on_disk_feature_ingest(tmp_path):
     assert len(tl) == 2 and all(v == v for v in tl) and tl[-1] < tl[0]
 
 
+def test_train_script_distill_cls(tmp_path):
+    """training.distill_cls=true adds "<teacher>_cls" Linear heads on the CLS token (train_rvfm.py:238-246)."""
+    from theia_amd.scripts.train import train_rvfm
+    hist = train_rvfm.main([
+        "dataset=synthetic", "training/target_models=dinov2", "+training.distill_cls=true",
+        "model.backbone.backbone=facebook/deit-tiny-patch16-224", "training.batch_size=4", "training.epochs=1",
+        "dataset.train_steps_per_epoch=10", "dataset.eval_steps_per_epoch=1", "training.base_lr=0.02", "+dataset.fixed_batch=true",
+        "precision=bf16", f"logging.model_path={tmp_path}", "+logging.log_interval=5",
+    ])
+    tl = [v for _, v in hist["train_main_loss"]]
+    assert len(tl) == 2 and all(v == v for v in tl) and tl[-1] < tl[0]
+
+
 def test_fused_adamw_matches_torch_adamw_over_steps():
     from theia_amd.optimizers import FusedAdamW, param_groups_weight_decay
     ma, teachers = _build()

@@ -350,6 +350,11 @@ class StudentEngine:
         C = D
         for t, hm in self.head_modules():
             pf = f"h:{t}."
+            if hm.kind == "cls":
+                Ct = hm.adapter["0"].weight.shape[0]
+                cb.add_cast(hm.adapter["0"].weight, new(pf + "w", Ct, C))
+                cb.add_transpose(hm.adapter["0"].weight, new(pf + "wT", C, Ct))
+                continue
             pad_plan = self._plan("pad")
             cb.add(hm.pad["1"].weight, new(pf + "pad.wf", C, 9 * C), *pad_plan.pack_fwd)
             cb.add(hm.pad["1"].weight, new(pf + "pad.wd", C, 9 * C), *pad_plan.pack_dgrad)
@@ -552,6 +557,11 @@ class StudentEngine:
         for t in names:
             hm = self._head(t)
             pf = f"h:{t}."
+            if hm.kind == "cls":  # Linear on token 0: rows of z with stride NTOK*C (adapter_heads.py:50-57)
+                outs.append(ops.linear(z[:, 0, :], oc[pf + "w"], hm.adapter["0"].bias))
+                if save:
+                    saved.append(None)
+                continue
             s0, s1, s2 = hm.sizes
             chw_ws = self.ws(N.lib().theia_layernorm_chw_workspace_bytes(b, s2 * s2 * C) // 4, dev)
             u1 = torch.empty(b, 256 * C, dtype=T, device=dev)
@@ -578,11 +588,32 @@ class StudentEngine:
         for hi, t in enumerate(names):
             dp = dpreds[hi]
             hm = self._head(t)
+            pf = f"h:{t}."
+            if hm.kind == "cls":
+                if dp is None:
+                    continue
+                lin = hm.adapter["0"]
+                Ct = lin.weight.shape[0]
+                dp = dp.contiguous().view(b, Ct)
+                if dp.dtype != T:
+                    raise TypeError(f"gradient dtype {dp.dtype} does not match the engine's compute dtype {T}")
+                z0, dz0 = z[:, 0, :], dz[:, 0, :]
+                if lin.weight.requires_grad:
+                    need = ops.wgrad_splits(b, Ct, C) * Ct * (C + 1)
+                    side = self._side_queue(dev, need)
+                    gw, accw = self._grad(lin.weight)
+                    gb, accb = self._grad(lin.bias)
+                    side.run(lambda dp=dp, z0=z0, gw=gw, accw=accw, gb=gb, accb=accb:
+                             ops.linear_wgrad(dp, z0, gw, accw, side.ws, bias=(gb, accb)), dp, z)
+                    ops.linear(dp, oc[pf + "wT"], out=dz0, resid=dz0)  # dz[:, 0] += dp @ W (several cls heads accumulate)
+                    self._bucket_done(self._bucket_of[id(lin.weight)][0], side)
+                else:
+                    ops.linear(dp, oc[pf + "wT"], out=dz0, resid=dz0)
+                continue
             bucket = self._bucket_of[id(hm.adapter["8"].weight)][0]
             if dp is None:
                 continue
             train = hm.adapter["8"].weight.requires_grad
-            pf = f"h:{t}."
             (u1, st0, v1, u2, st3, v2, u3, st6, v3) = saved["heads"][hi]
             saved["heads"][hi] = None
             s0, s1, s2 = hm.sizes

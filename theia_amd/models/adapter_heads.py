@@ -18,6 +18,28 @@ class _Slot(_Holder):
     """parameter-less positions of the reference's nn.Sequential (Rearrange / ReLU)."""
 
 
+class LinearAdapterHead(nn.Module):
+    """CLS-token distillation head: one Linear on token 0 (reference ``LinearAdapterHead`` adapter_heads.py:28-58;
+    ``adapter.0`` = nn.Linear(C, Ct)).  Parameter container; compute is in the HIP engine (``kind == "cls"``)."""
+
+    def __init__(self, source_size, target_size):
+        super().__init__()
+        self.source_size, self.target_size = tuple(source_size), tuple(target_size)
+        self.kind = "cls"
+        self.adapter = nn.ModuleDict({"0": LinearParams(int(source_size[0]), int(target_size[0]))})
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self) -> None:
+        lin = self.adapter["0"]
+        bound = 1.0 / math.sqrt(lin.weight.shape[1])
+        nn.init.uniform_(lin.weight, -bound, bound)
+        nn.init.uniform_(lin.bias, -bound, bound)
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("LinearAdapterHead holds parameters only; use the translator's forward")
+
+
 class LightConvAdapterHead(nn.Module):
     def __init__(self, source_size, target_size, hidden_size_factor: float = 1.0):
         super().__init__()

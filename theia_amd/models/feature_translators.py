@@ -9,7 +9,7 @@ from typing import Any, Optional
 import torch
 import torch.nn as nn
 
-from .adapter_heads import LightConvAdapterHead
+from .adapter_heads import LightConvAdapterHead, LinearAdapterHead
 
 
 class LightConvFeatureTranslator(nn.Module):
@@ -24,9 +24,10 @@ class LightConvFeatureTranslator(nn.Module):
         self.legit_target_model_name_map = {t: t.replace(".", "_") for t in self.target_model_names}
         heads = {}
         for t, size in target_feature_sizes.items():
-            if "_cls" in t:
-                raise NotImplementedError("CLS-token distillation heads are outside the round-1 hot path (SURVEY.md sec. 8f-5)")
-            heads[self.legit_target_model_name_map[t]] = LightConvAdapterHead(backbone_feature_size, size, hidden_size_factor)
+            if "_cls" in t:  # feature_translators.py:193-197: "<teacher>_cls" targets get a Linear head on the CLS token
+                heads[self.legit_target_model_name_map[t]] = LinearAdapterHead(backbone_feature_size, size)
+            else:
+                heads[self.legit_target_model_name_map[t]] = LightConvAdapterHead(backbone_feature_size, size, hidden_size_factor)
         self.translator_heads = nn.ModuleDict(heads)
         self._engine = None  # set by RobotVisionFM
 

@@ -64,17 +64,27 @@ class SyntheticFrames:
             return self._cached
         batch: dict[str, Any] = {"image": torch.randint(0, 256, (self.b, 224, 224, 3), dtype=torch.uint8, device=self.device,
                                                         generator=self.gen)}
+        spatial = [t for t in self.names if not t.endswith("_cls")]
         if self.ingest is not None:
             raw = {t: torch.randn((self.b,) + tuple(get_model_feature_size(t, keep_spatial=True)), generator=self.cpu_gen).to(torch.bfloat16)
-                   for t in self.names}
+                   for t in spatial}
             for t, emb in self.ingest(raw).items():
                 batch[t] = {"embedding": emb}
         else:
-            for t in self.names:
+            for t in spatial:
                 C, H, W = get_model_feature_size(t, keep_spatial=True)
                 batch[t] = {"embedding": torch.randn(self.b, H * W, C, device=self.device, generator=self.gen)}
+        for t in self.names:  # "<teacher>_cls": the teacher's CLS token rides in the teacher's sample dict (data_utils.py:156-160)
+            if t.endswith("_cls"):
+                Ct = get_model_feature_size(t[:-4], keep_spatial=True)[0]
+                batch.setdefault(t[:-4], {})["cls"] = torch.randn(self.b, Ct, device=self.device, generator=self.gen)
         self._cached = batch if self.fixed else None
         return batch
+
+
+def _targets_of(batch: dict, names) -> dict:
+    """train_rvfm.py:107-114: "<teacher>_cls" targets are the teacher's CLS token, everything else its spatial embedding."""
+    return {t: (batch[t[:-4]]["cls"] if t.endswith("_cls") else batch[t]["embedding"]).float() for t in names}
 
 
 def select_main_loss(losses: dict, main_loss: str | None):
@@ -100,7 +110,7 @@ def train(rvfm: nn.Module, target_model_names, optimizer, lr_scheduler, train_it
             images_batch = batch["image"]
             if cfg.training.random_target_models > 0:
                 raise NotImplementedError("random_target_models > 0 is not supported (breaks data-parallel reduction in the reference too)")
-            target_features_batch = {t: batch[t]["embedding"].float() for t in target_model_names}
+            target_features_batch = _targets_of(batch, target_model_names)
             pred = rvfm(images_batch)
             losses = rvfm.module.get_loss(pred, target_features_batch, as_float=False)
             main_loss = select_main_loss(losses, cfg.training.main_loss)
@@ -128,7 +138,7 @@ def train(rvfm: nn.Module, target_model_names, optimizer, lr_scheduler, train_it
             acc, n = 0.0, 0
             for _ in range(eval_epoch_steps):
                 batch = next(eval_iter)
-                target_features_batch = {t: batch[t]["embedding"].float() for t in target_model_names}
+                target_features_batch = _targets_of(batch, target_model_names)
                 pred = rvfm(batch["image"])
                 losses = rvfm.module.get_loss(pred, target_features_batch, as_float=False)
                 acc += float(select_main_loss(losses, cfg.training.main_loss))
@@ -174,8 +184,11 @@ def ddp_main(cfg) -> dict:
     target_model_names = list(names) if len(names) > 0 else list(MODEL_FEATURE_SIZES.keys())
     target_model_names = [t for t in target_model_names if "llava" not in t]
     target_feature_sizes = {t: get_model_feature_size(t, keep_spatial=True) for t in target_model_names}
-    if cfg.training.get("distill_cls", False):
-        raise NotImplementedError("CLS-token distillation heads are outside the hot path (SURVEY.md sec. 8f-5)")
+    if cfg.training.get("distill_cls", False):  # train_rvfm.py:238-246: CLS-token heads for the ViT / DINOv2 / CLIP teachers
+        for t in list(target_model_names):
+            if "google/vit" in t or "facebook/dino" in t or "openai/clip" in t:
+                target_feature_sizes[t + "_cls"] = get_model_feature_size(t, keep_spatial=True)[:1]
+                target_model_names.append(t + "_cls")
 
     rvfm = RobotVisionFM(translator=cfg.model.translator.type, translator_kwargs=cfg.model.translator.kwargs,
                          target_feature_sizes=target_feature_sizes,
