@@ -246,6 +246,43 @@ def gen_g12(RobotVisionFM, gmfs):
     np.savez_compressed(os.path.join(OUT, "g12_resize_processor.npz"), **fx)
 
 
+def gen_g14(RobotVisionFM, gmfs):
+    """The DeiT processor configuration of the hub checkpoints (preprocessor_config.json of facebook/deit-*-patch16-224:
+    resize 256 bicubic, center-crop 224, ImageNet mean/std; transformers' DeiTImageProcessor) plugged into the reference
+    model in place of the offline shim's ViT processor: resized+cropped uint8 rows, pixel_values rows, forward_feature."""
+    print("[gen_golden] G14", flush=True)
+    from transformers.models.deit.image_processing_pil_deit import DeiTImageProcessorPil
+    backbone = "facebook/deit-tiny-patch16-224"
+    teachers = O.TEACHER_SETS["dinov2"]
+    model, params = build_reference(RobotVisionFM, gmfs, backbone, teachers)
+    model.eval()
+    proc = DeiTImageProcessorPil(image_mean=list(O.IMAGENET_MEAN), image_std=list(O.IMAGENET_STD))
+    assert proc.size["height"] == 256 and proc.crop_size["height"] == 224 and int(proc.resample) == 3 and proc.do_center_crop
+    model.backbone.processor = proc
+    fx = {}
+    rows = np.arange(0, 224, 7)
+    for name, (b, hh, ww) in {"in224": (2, 224, 224), "in300x260": (1, 300, 260)}.items():
+        img = torch.from_numpy((O._hash_uniform(b * hh * ww * 3, 500 + hh) * 0.5 + 0.5).reshape(b, hh, ww, 3) * 255.999).to(torch.uint8)
+        if name == "in224":
+            img = O.synth_images(b, 0)
+        else:
+            fx[f"{name}_img"] = img.numpy()
+        with torch.no_grad():
+            raw = proc(img, return_tensors="pt", do_rescale=False, do_normalize=False)["pixel_values"]
+            pv = proc(img, return_tensors="pt")["pixel_values"]
+            z = model.forward_feature(img)
+        r8 = raw.permute(0, 2, 3, 1).to(torch.uint8).numpy()
+        fx[f"{name}_u8_rows"] = r8[:, rows]
+        fx[f"{name}_u8_sum"] = np.array(r8.astype(np.int64).sum())
+        fx[f"{name}_pv_rows"] = pv.permute(0, 2, 3, 1).numpy()[:, rows[::4]]
+        zi = sample_idx(z.numel(), 64, 17)
+        fx[f"{name}_z_idx"] = zi
+        fx[f"{name}_z_val"] = z.numpy().reshape(-1)[zi]
+        fx[f"{name}_z_abssum"] = np.array(np.abs(z.numpy().astype(np.float64)).sum())
+    fx["rows"] = rows
+    np.savez_compressed(os.path.join(OUT, "g14_deit_processor.npz"), **fx)
+
+
 def gen_g8():
     print("[gen_golden] G8", flush=True)
     sys.path.insert(0, REF_SRC)
@@ -406,6 +443,8 @@ def main():
         gen_g8()
     if want("g12"):
         gen_g12(RobotVisionFM, gmfs)
+    if want("g14"):
+        gen_g14(RobotVisionFM, gmfs)
     if want("g10"):
         gen_g10()
     if want("g11"):

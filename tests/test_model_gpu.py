@@ -195,6 +195,32 @@ def test_non_224_inputs_go_through_the_processor_resize(golden_dir):
         m.forward_feature(torch.from_numpy(a[None]), do_resize=False)
 
 
+def test_deit_hub_processor_configuration(golden_dir):
+    """processor="deit": resize 256 bicubic + center-crop 224 (the hub checkpoints' preprocessor_config) -- forward_feature
+    against the reference model run with transformers' DeiTImageProcessor (golden G14), 224 and non-224 inputs."""
+    from theia_amd.models.rvfm import RobotVisionFM
+    from theia_amd.foundation_models.common import get_model_feature_size
+    g = np.load(os.path.join(golden_dir, "g14_deit_processor.npz"))
+    bb, teachers = "facebook/deit-tiny-patch16-224", O.TEACHER_SETS["dinov2"]
+    m = RobotVisionFM(backbone=bb, translator="lconv", translator_kwargs={"hidden_size_factor": 1.0},
+                      target_feature_sizes={t: get_model_feature_size(t, keep_spatial=True) for t in teachers},
+                      precision="fp32", processor="deit")
+    m.load_state_dict(O.synth_params(bb, teachers, 0), strict=True)
+    m = m.to("cuda:0")
+    assert m.backbone.resize_size == (256, 256) and m.backbone.crop_size == 224 and m.backbone.resample == 3
+    for name, img in (("in224", O.synth_images(2, 0)), ("in300x260", torch.from_numpy(g["in300x260_img"]))):
+        with torch.no_grad():
+            z = m.forward_feature(img).float().cpu().numpy()
+        assert rel(np.abs(z.astype(np.float64)).sum(), float(g[f"{name}_z_abssum"])) < 1e-4, name
+        assert np.allclose(z.reshape(-1)[g[f"{name}_z_idx"]], g[f"{name}_z_val"], rtol=1e-3, atol=2e-4), name
+    # back to the default processor: 224x224 input is an identity again
+    m.backbone.set_processor()
+    with torch.no_grad():
+        z0 = m.forward_feature(O.synth_images(2, 0))
+    g1 = np.load(os.path.join(golden_dir, "g6_g7_tokens_layouts.npz"))
+    assert z0.shape[1] == 196
+
+
 def test_grad_accumulation_and_freeze_translator():
     bb, teachers = "facebook/deit-tiny-patch16-224", O.TEACHER_SETS["dinov2"]
     model, _ = build(bb, teachers, "fp32")

@@ -48,3 +48,17 @@ def test_product_tables_match_restatement(resample):
             b0, k0, ks0 = R.precompute_coeffs(i, o, resample)
             b1, k1, ks1 = resample_tables(i, o, resample)
             assert ks0 == ks1 and np.array_equal(b0, b1) and np.array_equal(k0, k1), (i, o)
+
+
+def test_deit_hub_processor_pipeline_g14(golden_dir):
+    """resize 256 bicubic + center-crop 224 + rescale/normalise (the facebook/deit-*-patch16-224 preprocessor_config) as the
+    reference's processor class computes it, against the restatement (resize -> crop -> table)."""
+    g = np.load(os.path.join(golden_dir, "g14_deit_processor.npz"))
+    rows = g["rows"]
+    lut = O.preprocess_lut(True, True)
+    for name, img in (("in224", O.synth_images(2, 0).numpy()), ("in300x260", g["in300x260_img"])):
+        out = np.stack([R.resize_u8(np.ascontiguousarray(im), 256, 256, R.BICUBIC)[16:240, 16:240] for im in img])
+        assert np.array_equal(out[:, rows], g[f"{name}_u8_rows"]), name
+        assert int(out.astype(np.int64).sum()) == int(g[f"{name}_u8_sum"])
+        pv = np.stack([lut[c][out[..., c]] for c in range(3)], -1)
+        assert np.array_equal(pv[:, rows[::4]], g[f"{name}_pv_rows"]), name

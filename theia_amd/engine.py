@@ -80,8 +80,7 @@ def to_uint8_batch(x: Any, any_size: bool = False):
         raise ValueError(f"expected 3-channel images, got shape {tuple(x.shape)}")
     hh, ww = (x.shape[1], x.shape[2]) if channels_last else (x.shape[2], x.shape[3])
     if not any_size and (hh != IMAGE or ww != IMAGE):
-        raise NotImplementedError(f"{hh}x{ww} input with do_resize=False: position-embedding interpolation is outside the hot "
-                                  f"path (SURVEY.md sec. 8f-3); feed {IMAGE}x{IMAGE} images or keep do_resize=True")
+        raise NotImplementedError(f"{hh}x{ww} input: feed {IMAGE}x{IMAGE} images")
     return x.contiguous(), channels_last
 
 
@@ -378,35 +377,45 @@ class StudentEngine:
         device = vit.layernorm.weight.device
         if device.type != "cuda":
             raise RuntimeError("theia_amd runs on a ROCm GPU only: move the model with .to('cuda') (no CPU fallback)")
-        batch = to_uint8_batch(x, any_size=do_resize)
-        img, channels_last = self._to_model_size(batch, device)
+        batch = to_uint8_batch(x, any_size=True)
+        img, channels_last = self._to_model_size(batch, device, do_resize)
         params = list(vit.parameters())
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _BackboneFn.apply(self, img, channels_last, do_rescale, do_normalize, *params)
         z, _ = self._backbone_fwd(img, channels_last, do_rescale, do_normalize, save=False)
         return z
 
-    def _to_model_size(self, batch, device) -> Tuple[torch.Tensor, bool]:
-        """The processor's resize step (backbones.py:337-339 with do_resize=True): anything that is not 224x224 goes through
-        theia_resize_u8 (Pillow's resampling, bit-exact) on the GPU; 224x224 input passes through untouched."""
-        resample = int(getattr(self.rvfm.backbone, "resample", 2))
+    def _to_model_size(self, batch, device, do_resize: bool = True) -> Tuple[torch.Tensor, bool]:
+        """The processor's resize and center-crop steps (backbones.py:337-339; order resize -> crop as in the HF processor):
+        theia_resize_u8 (Pillow's resampling, bit-exact) on the GPU to the configured size when do_resize, then the
+        center crop (top = (H - crop) // 2).  Images already at the final size pass through untouched."""
+        bb = self.rvfm.backbone
+        (rh, rw), crop, resample = bb.resize_size, bb.crop_size, bb.resample
+
+        def one(t: torch.Tensor, cl: bool) -> torch.Tensor:
+            t = t.to(device, non_blocking=True)
+            hh, ww = (t.shape[1], t.shape[2]) if cl else (t.shape[2], t.shape[3])
+            if do_resize and (hh, ww) != (rh, rw):
+                t, cl, hh, ww = ops.resize_u8(t, cl, rh, rw, resample), True, rh, rw
+            if crop is not None and (hh, ww) != (crop, crop):
+                if hh < crop or ww < crop:
+                    raise NotImplementedError(f"center-crop {crop} of a {hh}x{ww} image (the HF processor zero-pads) is not implemented")
+                top, left = (hh - crop) // 2, (ww - crop) // 2
+                t = t[:, top:top + crop, left:left + crop, :] if cl else t[:, :, top:top + crop, left:left + crop]
+                hh = ww = crop
+            if (hh, ww) != (IMAGE, IMAGE):
+                raise NotImplementedError(f"{hh}x{ww} after the processor: position-embedding interpolation is outside the hot "
+                                          f"path (SURVEY.md sec. 8f-3); feed {IMAGE}x{IMAGE} images or keep do_resize=True")
+            return t, cl
+
         if isinstance(batch, list):  # items of different sizes: one resize launch per item, then one batch
             outs = []
             for t, cl in batch:
-                t = t.to(device, non_blocking=True)
-                hh, ww = (t.shape[1], t.shape[2]) if cl else (t.shape[2], t.shape[3])
-                if (hh, ww) != (IMAGE, IMAGE):
-                    t = ops.resize_u8(t, cl, IMAGE, IMAGE, resample)
-                elif not cl:
-                    t = t.permute(0, 2, 3, 1).contiguous()
-                outs.append(t)
+                t, cl = one(t, cl)
+                outs.append(t if cl else t.permute(0, 2, 3, 1))
             return torch.cat(outs, 0).contiguous(), True
-        img, channels_last = batch
-        img = img.to(device, non_blocking=True)
-        hh, ww = (img.shape[1], img.shape[2]) if channels_last else (img.shape[2], img.shape[3])
-        if (hh, ww) != (IMAGE, IMAGE):
-            return ops.resize_u8(img, channels_last, IMAGE, IMAGE, resample), True
-        return img, channels_last
+        img, cl = one(*batch)
+        return img.contiguous(), cl
 
     def _backbone_fwd(self, img: torch.Tensor, channels_last: bool, do_rescale: bool, do_normalize: bool, save: bool):
         dev, T, D, F, nh = img.device, self.dtype, self.D, self.F, self.heads

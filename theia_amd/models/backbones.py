@@ -134,11 +134,16 @@ def remap_legacy_key(k: str) -> str:
     return k
 
 
+DEIT_HUB_PROCESSOR = {"size": 256, "crop_size": 224, "resample": 3,
+                      "image_mean": (0.485, 0.456, 0.406), "image_std": (0.229, 0.224, 0.225)}
+
+
 class DeiT(nn.Module):
     """DeiT student (reference ``DeiT`` backbones.py:255-341).  ``forward`` takes uint8 images and returns the last
     hidden state [B, 197, D]; image preprocessing (rescale + normalise) is fused into the ingest kernel."""
 
-    def __init__(self, model_name: str = "facebook/deit-small-patch16-224", pretrained: bool = False, image_size: int = 224):
+    def __init__(self, model_name: str = "facebook/deit-small-patch16-224", pretrained: bool = False, image_size: int = 224,
+                 processor: Optional[dict] = None):
         super().__init__()
         if model_name not in ARCH:
             raise NotImplementedError(f"Requested {model_name} is not implemented.")
@@ -149,11 +154,28 @@ class DeiT(nn.Module):
         self.image_size = image_size
         D, heads, F = ARCH[model_name]
         self.model = ViTParams(D, heads, F)
-        # explicit processor configuration: 224, no crop, ImageNet mean/std
-        self.image_mean = (0.485, 0.456, 0.406)
-        self.image_std = (0.229, 0.224, 0.225)
-        self.resample = 2  # PIL BILINEAR (ViTImageProcessor default); 3 = BICUBIC (DeiTImageProcessor class default)
         self._engine = None  # set by RobotVisionFM
+        # The reference takes its image processor from the hub (AutoProcessor.from_pretrained, backbones.py:292); nothing can
+        # be fetched here, so the configuration is explicit.  Default: resize to 224x224 bilinear, no
+        # crop, ImageNet mean/std (the ViT processor the golden vectors were generated with).  processor="deit" (or a dict)
+        # selects the preprocessor_config.json of the facebook/deit-*-patch16-224 checkpoints: resize 256 bicubic +
+        # center-crop 224 (transformers DeiTImageProcessor; golden G14).
+        self.set_processor(**({} if processor is None else DEIT_HUB_PROCESSOR if processor == "deit" else dict(processor)))
+
+    def set_processor(self, size=224, crop_size: Optional[int] = None, resample: int = 2,
+                      image_mean=(0.485, 0.456, 0.406), image_std=(0.229, 0.224, 0.225)) -> None:
+        """size: int or (h, w) the resize target; crop_size: center-crop edge or None; resample: 2 bilinear / 3 bicubic."""
+        self.resize_size = (int(size), int(size)) if isinstance(size, int) else (int(size[0]), int(size[1]))
+        self.crop_size = None if crop_size is None else int(crop_size)
+        if resample not in (2, 3):
+            raise NotImplementedError(f"resample={resample}: PIL BILINEAR (2) and BICUBIC (3) are implemented")
+        self.resample = int(resample)
+        final = (self.crop_size, self.crop_size) if self.crop_size else self.resize_size
+        if final != (224, 224):
+            raise NotImplementedError(f"processor output {final}: the student consumes 224x224 (no pos-emb interpolation)")
+        self.image_mean, self.image_std = tuple(float(v) for v in image_mean), tuple(float(v) for v in image_std)
+        if self._engine is not None:
+            self._engine._luts.clear()
 
     def get_feature_size(self, keep_spatial: bool = False, return_torch_size: bool = False):
         D = self.model.hidden_size
@@ -179,5 +201,5 @@ def build_backbone(model_name: str, pretrained: bool = False, image_size: int = 
     if "reg" in model_name or "nocls" in model_name:
         raise NotImplementedError(f"{model_name}: register-token / no-CLS variants are not part of the hot path yet")
     if "deit" in model_name:
-        return DeiT(model_name=model_name, pretrained=pretrained, image_size=image_size)
+        return DeiT(model_name=model_name, pretrained=pretrained, image_size=image_size, processor=kwargs.get("processor"))
     raise NotImplementedError(f"Requested {model_name} is not implemented.")
