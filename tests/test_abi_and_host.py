@@ -37,6 +37,48 @@ def test_struct_layout_matches_header():
     assert C.sizeof(N.GemmArgs) == 8 * 8 + 4 * 7 + 4 + C.sizeof(N.RowMap)  # 8 pointers, 7 int32 + pad, map
 
 
+def test_host_side_planning_functions():
+    """Pure host entry points of the library (no launch): cast-batch scheduling, weight-gradient splits, bias fusion query."""
+    from theia_amd import _native as N
+    lib = N.lib()
+    assert C.sizeof(N.CastJob) == 2 * 8 + 4 * 4 + 5 * 8 + 8 + 4 * 4
+    jobs = (N.CastJob * 4)()
+    shapes = [(1, 100, 72, 0, 72, 1), (1, 72, 100, 0, 1, 72), (48, 9, 48, 9 * 48, 1, 9), (1, 1, 77, 0, 77, 1)]
+    for j, (d0, d1, d2, s0, s1, s2) in zip(jobs, shapes):
+        j.src, j.dst, j.d0, j.d1, j.d2, j.s0, j.s1, j.s2, j.t0, j.t1 = 4096, 8192, d0, d1, d2, s0, s1, s2, d1 * d2, d2
+    total = lib.theia_cast_batch_plan(C.addressof(jobs), 4)
+    blocks = 0
+    for j, (d0, d1, d2, *_s) in zip(jobs, shapes):
+        assert j.tile1 * j.tile2 == 4096 and j.tile2 % 4 == 0 and j.first_block == blocks
+        assert j.tiles1 == -(-d1 // j.tile1) and j.tiles2 == -(-d2 // j.tile2)
+        blocks += d0 * j.tiles1 * j.tiles2
+    assert total == blocks
+    assert [j.tile1 for j in jobs] == [64, 64, 16, 1]
+    jobs[1].d1 = 0
+    assert lib.theia_cast_batch_plan(C.addressof(jobs), 4) == -1
+    # weight-gradient planning: the ping-pong kernel fills one round of 256 CUs; small shapes fall back
+    assert lib.theia_wgrad_splits(25216, 768, 768) == 28 and lib.theia_wgrad_splits(25216, 3072, 768) == 7
+    assert lib.theia_wgrad_splits(32768, 768, 6912) == 3 and lib.theia_wgrad_splits(128, 1024, 768) == 1
+    w = N.WgradArgs()
+    w.N, w.map.in_c = 768, 768
+    assert lib.theia_wgrad_fuses_bias(w, N.BF16) == 1 and lib.theia_wgrad_fuses_bias(w, N.F32) == 0
+    w.map.in_c = 64
+    assert lib.theia_wgrad_fuses_bias(w, N.BF16) == 0
+    assert lib.theia_gemm_nt_tile(25216, 768, N.BF16) == 256256 and lib.theia_gemm_nt_tile(100, 64, N.BF16) in (128064, 128128)
+
+
+def test_resize_plan_tables_are_consistent():
+    from theia_amd.preprocess import resample_tables
+    for in_size, out_size, rs in ((300, 224, 2), (50, 224, 3), (1000, 224, 2), (224, 256, 3), (7, 224, 2)):
+        bounds, w, ksize = resample_tables(in_size, out_size, rs)
+        assert bounds.shape == (out_size, 2) and w.shape == (out_size, ksize)
+        assert (bounds[:, 0] >= 0).all() and (bounds[:, 0] + bounds[:, 1] <= in_size).all() and (bounds[:, 1] >= 1).all()
+        sums = w.astype(np.int64).sum(1)
+        assert np.abs(sums - (1 << 22)).max() <= ksize  # weights sum to 1.0 in 22-bit fixed point up to per-tap rounding
+        live = np.arange(ksize)[None, :] < bounds[:, 1:2]
+        assert (w[~live] == 0).all()
+
+
 def test_argument_validation_errors_without_gpu():
     from theia_amd import _native as N
     lib = N.lib()
