@@ -1,35 +1,48 @@
 #!/usr/bin/env python
 """bench.py -- images/sec of one Theia distillation train step on MI355X (the BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W            (N == 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W               (N > 1, one rank per GPU over RCCL)
+    python bench.py --gpus N --steps K --warmup W
+
+N == 1 runs in this process.  N > 1 without WORLD_SIZE in the environment re-launches itself as
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...``
+(one rank per GPU over RCCL); launched that way by someone else (RANK / WORLD_SIZE set) it just runs as a rank.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): DeiT-base-patch16-224 student, 5
 teachers (cddsv: ViT-H, DINOv2-L, CLIP-L, SAM-H, Depth-Anything-L), bf16 MFMA operands / f32 accumulate / f32 master
 weights, per-GPU batch 128 (global 1024 at 8 GPUs -> weak scaling), loss 0.9*cos + 0.1*smooth-L1.
 One step = forward + loss + backward + gradient all-reduce (RCCL, overlapped) + fused AdamW update, on synthetic
 uint8 224x224x3 images and random f32 teacher features already resident in HBM.  Random-init weights.
+``--mode forward_feature`` measures BASELINE configs[4] instead (see forward_feature_main).
+
+Before anything is timed the run CHECKS ITSELF and refuses to report a value if a check fails:
+  1. rank 0: one bf16 step of the same architecture at batch 2 with every GEMM forced onto the 256x256 ping-pong kernel
+     (the kernel the batch-128 step runs on) against the CPU oracle's fp32 losses and gradients;
+  2. every rank: the step at the bench batch with the library's own dispatch against the same step with every GEMM
+     forced onto the 2-stage 128x128 kernel (the one the small-shape oracle tests use by default).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel = the theia_gemm_nt tile variant with the largest share of the step (MFMA-bound): algorithmic FLOPs of its launches /
-                their HIP-event-measured duration (events on the launch stream, taken in extra instrumented steps
-                right after the timed region so the timed steps stay unperturbed)
-  cpu_baseline  the CPU oracle (oracle/theia_oracle.py, torch fp32 on the host cores) on a bounded sample of the
-                same workload (same model / teachers / loss, batch 2, 2 steps, <= 32 threads), rank 0, N == 1 only
+  roofline          dominant kernel = the theia_gemm_nt tile variant with the largest share of the step (MFMA-bound):
+                    algorithmic FLOPs of its launches / their HIP-event-measured duration (events on the launch stream,
+                    taken in extra instrumented steps right after the timed region so the timed steps stay unperturbed)
+  student_roofline  DeiT-base student alone, forward + backward (north_star's ">= 40 % of bf16 MFMA peak" claim):
+                    105.147 GFLOP per image / HIP-event time of backbone forward+backward
+  cpu_baseline      SURVEY 8(d): the CPU oracle (oracle/theia_oracle.py, torch fp32) running BASELINE configs[0] exactly
+                    (DeiT-tiny, dinov2-large, batch 8, 10 warm-up + 50 timed steps, median) on the host's physical cores;
+                    rank 0, N == 1 only.  The base+5-teacher oracle step of self-check 1 is reported beside it.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -42,11 +55,14 @@ TEACHERS = [
     "facebook/sam-vit-huge",
     "LiheYoung/depth-anything-large-hf",
 ]
-FLOPS_PER_IMAGE_FWD_BWD = 272.169e9  # BASELINE.md sec. 3 (2xMAC, fwd+bwd, base + cddsv)
-MFMA_BF16_PEAK = 2.5e15              # dense, /opt/skills/guides/MI355X_MICROARCH.md
+FLOPS_PER_IMAGE_FWD_BWD = 272.169e9   # BASELINE.md sec. 3 (2xMAC, fwd+bwd, base + cddsv)
+FLOPS_PER_IMAGE_STUDENT = 105.147e9   # DeiT-base backbone only, fwd+bwd
+FLOPS_PER_IMAGE_FWD = 35.126e9        # DeiT-base forward
+MFMA_BF16_PEAK = 2.5e15               # dense, /opt/skills/guides/MI355X_MICROARCH.md
+METRIC = "images/sec train-step (fwd+bwd+allreduce) DeiT-base 5-teacher"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -54,30 +70,14 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--backbone", default=BACKBONE)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--mode", default="train", choices=["train", "forward_feature"])
+    ap.add_argument("--chunk", type=int, default=512, help="forward_feature: images per captured graph replay")
+    ap.add_argument("--stream-batch", type=int, default=4096, help="forward_feature: images streamed per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-selfcheck", action="store_true", help="tuning runs only: the printed line is marked unchecked")
     ap.add_argument("--no-optimizer", action="store_true", help="exclude the AdamW update from the step")
-    return ap.parse_args()
-
-
-def cpu_baseline(backbone, teachers):
-    """Oracle (CPU restatement) timed on the host cores: bounded sample of the same workload."""
-    from oracle import theia_oracle as O
-    # 32 threads: torch's CPU kernels stop scaling (and thrash on 256-core hosts) beyond that for these op sizes
-    cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
-    B = 2
-    params = O.synth_params(backbone, teachers, 0)
-    images = O.synth_images(B, 0)
-    targets = O.synth_targets(B, teachers, 1)
-    O.train_step_grads(params, images[:1], {t: v[:1] for t, v in targets.items()}, backbone, teachers)  # warm-up
-    n = 2
-    t0 = time.perf_counter()
-    for _ in range(n):
-        O.train_step_grads(params, images, targets, backbone, teachers)
-    dt = time.perf_counter() - t0
-    return {"value": round(n * B / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} fwd+loss+bwd steps of {backbone.split('/')[-1]} + 5 teachers at batch {B} (fp32 torch CPU oracle, no optimizer)"}
+    return ap.parse_args(argv)
 
 
 def log(msg):
@@ -85,8 +85,195 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def main():
-    args = parse()
+# ------------------------------------------------------------------------------------------------ N > 1 launch
+def self_spawn(args, argv) -> None:
+    """--gpus N > 1 outside a torch.distributed launch: become the launcher (one rank per GPU, RCCL)."""
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "images/sec", "n_gpus": args.gpus,
+                          "error": f"--gpus {args.gpus} but only {ndev} GPU(s) are visible"}), flush=True)
+        raise SystemExit(2)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log("launching " + " ".join(cmd))
+    raise SystemExit(subprocess.call(cmd))
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def host_cpu():
+    """(physical cores available to this process, CPU model string)"""
+    model, cores = "unknown", set()
+    try:
+        allowed = os.sched_getaffinity(0)
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if "processor" in cur and int(cur["processor"]) in allowed:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur["processor"])))
+                cur = {}
+                continue
+            k, v = [x.strip() for x in line.split(":", 1)]
+            cur[k] = v
+            if k == "model name":
+                model = v
+        if "processor" in cur and int(cur["processor"]) in allowed:
+            cores.add((cur.get("physical id", "0"), cur.get("core id", cur["processor"])))
+    except Exception:
+        pass
+    n = len(cores) or (os.cpu_count() or 1)
+    return n, model
+
+
+def cpu_baseline(extra=None):
+    """SURVEY 8(d) protocol: BASELINE configs[0] exactly -- DeiT-tiny, 1 teacher (dinov2-large), batch 8, fp32, world 1,
+    fwd + loss + bwd, 10 warm-up + 50 timed steps, median step time, torch threads = physical cores."""
+    import torch
+    from oracle import theia_oracle as O
+    cores, cpu_model = host_cpu()
+    bb, teachers, B = "facebook/deit-tiny-patch16-224", O.TEACHER_SETS["dinov2"], 8
+    params = O.synth_params(bb, teachers, 0)
+    images = O.synth_images(B, 0)
+    targets = O.synth_targets(B, teachers, 1)
+
+    def run(threads, warm, timed):
+        torch.set_num_threads(threads)
+        for _ in range(warm):
+            O.train_step_grads(params, images, targets, bb, teachers)
+        ts = []
+        for _ in range(timed):
+            t0 = time.perf_counter()
+            O.train_step_grads(params, images, targets, bb, teachers)
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
+    med = run(cores, 10, 50)
+    out = {"value": round(B / med, 2), "unit": "images/sec", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+           "sample": "BASELINE configs[0]: DeiT-tiny + dinov2-large, batch 8, fp32, fwd+loss+bwd (no optimizer), 10 warm-up + 50 timed "
+                     f"steps, median step {med * 1e3:.1f} ms, torch.set_num_threads({cores}) = physical cores"}
+    if cores > 32:  # torch's CPU kernels stop scaling around 32 threads for these op sizes: report the better setting too
+        med32 = run(32, 3, 15)
+        out["value_32_threads"] = round(B / med32, 2)
+    if extra:
+        out.update(extra)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ self-checks
+def _cos(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def selfcheck_oracle(backbone, precision, dev):
+    """bf16 step at batch 2, every GEMM on the ping-pong kernel, against the CPU oracle (fp32).  Returns (report, cpu sample)."""
+    import torch
+    from oracle import theia_oracle as O  # checker only
+    from theia_amd import ops
+    from theia_amd.foundation_models.common import get_model_feature_size
+    from theia_amd.models.rvfm import RobotVisionFM
+    B = 2
+    m = RobotVisionFM(backbone=backbone, translator="lconv", translator_kwargs={"hidden_size_factor": 1.0},
+                      target_feature_sizes={t: get_model_feature_size(t, keep_spatial=True) for t in TEACHERS}, precision=precision)
+    params = O.synth_params(backbone, TEACHERS, 0)
+    m.load_state_dict(params, strict=True)
+    m = m.to(dev)
+    images = O.synth_images(B, 0)
+    tcpu = O.synth_targets(B, TEACHERS, 1)
+    prev, ops.GEMM_TILE_HINT = ops.GEMM_TILE_HINT, 256256
+    try:
+        losses = m.get_loss(m(images), {t: v.to(dev) for t, v in tcpu.items()})
+        main = 0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]
+        main.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.GEMM_TILE_HINT = prev
+    cores, _ = host_cpu()
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    _, ref_main, grads, _ = O.train_step_grads(params, images, tcpu, backbone, TEACHERS, "cos_l1")
+    dt_cpu = time.perf_counter() - t0
+    tol = 2e-2 if precision == "bf16" else 1e-4
+    rel = abs(float(main) - float(ref_main)) / abs(float(ref_main))
+    worst, who = 1.0, ""
+    for k, p in m.named_parameters():
+        if grads[k].numel() < 4096 or "k_proj" in k:
+            continue
+        c = _cos(p.grad.detach().float().cpu(), grads[k])
+        if c < worst:
+            worst, who = c, k
+    ok = rel < tol and worst > (0.98 if precision == "bf16" else 0.9999)
+    rep = {"ok": bool(ok), "batch": B, "loss_rel_err": float(f"{rel:.3e}"), "worst_grad_cosine": round(worst, 5), "worst_param": who,
+           "tile": "256x256 forced"}
+    sample = {"oracle_step_same_model": {"value": round(B / dt_cpu, 3), "unit": "images/sec", "cores": cores,
+                                         "sample": f"1 fwd+loss+bwd step of {backbone.split('/')[-1]} + 5 teachers at batch {B} (fp32 oracle)"}}
+    del m
+    torch.cuda.empty_cache()
+    return rep, sample
+
+
+def selfcheck_dispatch(fwd_bwd, engine):
+    """the bench-size step: library dispatch vs every GEMM on the 2-stage 128x128 kernel"""
+    import torch
+    from theia_amd import ops
+    la = float(fwd_bwd().detach().float())
+    torch.cuda.synchronize()
+    snap = [b.flat.clone() for b in engine.buckets if b.flat is not None]
+    prev, ops.GEMM_TILE_HINT = ops.GEMM_TILE_HINT, 128128
+    try:
+        lb = float(fwd_bwd().detach().float())
+        torch.cuda.synchronize()
+    finally:
+        ops.GEMM_TILE_HINT = prev
+    cur = [b.flat for b in engine.buckets if b.flat is not None]
+    worst = min(_cos(a, b) for a, b in zip(snap, cur))
+    rel = abs(la - lb) / abs(lb)
+    return {"ok": bool(rel < 2e-3 and worst > 0.999), "loss_rel_diff": float(f"{rel:.3e}"), "worst_bucket_cosine": round(worst, 6)}
+
+
+def src_sha(files):
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+NT_KERNEL_SOURCES = ["theia_amd/csrc/gemm_pp.hip", "theia_amd/csrc/gemm_tile.h", "theia_amd/csrc/gemm.hip"]
+
+
+def load_traffic(pfx):
+    """HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read inside a timed run, so the number
+    comes from the committed summary of tools/pmc_bench_traffic.sh -- and only if that summary was taken from the kernel
+    sources this run was built from (it records their hash); otherwise null."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_bench_pmc_traffic.json"):
+            best = os.path.join(pdir, name)  # highest round wins
+    if best is None:
+        return None, None
+    try:
+        tj = json.load(open(best))
+        if tj.get("_kernel_src_sha") != src_sha(NT_KERNEL_SOURCES):
+            return None, os.path.basename(best) + " (stale: kernel sources changed since it was taken)"
+        key = [k for k in tj if k.startswith("gemm_nt_pp_kernel") and (("bf16" in k) == (pfx == "bf16"))]
+        return (tj[key[0]]["hbm_bytes_per_launch"] if key else None), os.path.basename(best)
+    except Exception:  # a malformed summary must not break the benchmark
+        return None, None
+
+
+# ------------------------------------------------------------------------------------------------ train-step bench
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        self_spawn(args, argv)
+    import torch
+    import torch.distributed as dist
     if os.environ.get("THEIA_BENCH_DEBUG"):  # dump every thread's stack if the run is still going after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["THEIA_BENCH_DEBUG"]), exit=True)
@@ -94,28 +281,43 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (see the docstring)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # test hook (not a product path): THEIA_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 over gloo, so that the N>1 code path
     # of this script (rendezvous, barriers, bucket all-reduces, max-over-ranks timing) can be smoke-tested on a 1-GPU box
-    # (gloo with device tensors and two processes per GPU dead-locks sporadically on this stack: use THEIA_BENCH_DEBUG=<s>)
     one_device = os.environ.get("THEIA_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_device:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)  # the first collective: counts the ranks RCCL actually connected
+        rccl_ranks = int(one.item())
+        log(f"process group up: backend {dist.get_backend()}, {rccl_ranks} ranks answered the first all-reduce")
+    if args.mode == "forward_feature":
+        return forward_feature_main(args, rank, world, dev)
 
     from theia_amd import ops
     from theia_amd.foundation_models.common import get_model_feature_size
     from theia_amd.models.rvfm import RobotVisionFM
     from theia_amd.optimizers import FusedAdamW
     from theia_amd.parallel import TheiaDataParallel
+
+    checks = {}
+    cpu_extra = None
+    if not args.no_selfcheck:
+        if rank == 0:
+            log("self-check 1: batch-2 step on the ping-pong kernels vs the CPU oracle ...")
+            checks["oracle"], cpu_extra = selfcheck_oracle(args.backbone, args.precision, dev)
+            log(f"self-check 1: {checks['oracle']}")
+        if world > 1:
+            dist.barrier()
 
     torch.manual_seed(0)
     model = RobotVisionFM(backbone=args.backbone, translator="lconv", translator_kwargs={"hidden_size_factor": 1.0},
@@ -134,17 +336,35 @@ def main():
         C, H, W = get_model_feature_size(t, keep_spatial=True)
         targets[t] = torch.randn(b, H * W, C, generator=g2).to(dev)
 
-    def step():
+    def fwd_bwd():
         opt.zero_grad(set_to_none=True)
         pred = ddp(images)
         losses = model.get_loss(pred, targets, as_float=False)
         main_loss = 0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]
         main_loss.backward()
+        return main_loss
+
+    def step():
+        main_loss = fwd_bwd()
         if not args.no_optimizer:
             opt.step()
         return main_loss
 
     log("inputs ready")
+    if not args.no_selfcheck:
+        checks["dispatch"] = selfcheck_dispatch(fwd_bwd, model.engine)
+        log(f"self-check 2: {checks['dispatch']}")
+    ok_flag = torch.tensor([1.0 if all(c["ok"] for c in checks.values()) else 0.0], device=dev)
+    if world > 1:
+        dist.all_reduce(ok_flag, op=dist.ReduceOp.MIN)
+    if float(ok_flag.item()) < 0.5:
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "images/sec", "n_gpus": world, "selfcheck": checks,
+                              "error": "self-check failed: the kernels of this run do not reproduce the oracle; no value reported"}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit(1)
+
     for i in range(args.warmup):
         step()
         torch.cuda.synchronize()
@@ -194,7 +414,7 @@ def main():
     torch.cuda.synchronize()
     log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step (host enqueue of one step: {host_dt * 1e3:.2f} ms)")
 
-    roofline = None
+    roofline = student = None
     if not args.no_roofline:
         pfx = "bf16" if args.precision == "bf16" else "f32"
 
@@ -207,22 +427,28 @@ def main():
             recs, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
             return [(e0.elapsed_time(e1) * 1e-3, fl, var, shp) for (e0, e1, fl, var, shp) in recs]
 
+        def table(label, rr, NP):
+            by = {}
+            for t_, fl, var, shp in rr:
+                d = by.setdefault((var,) + shp, [0, 0.0, 0.0])
+                d[0] += 1
+                d[1] += t_
+                d[2] += fl
+            log(f"{label}: total {sum(v[1] for v in by.values()) / NP * 1e3:.2f} ms/step, "
+                f"{sum(v[2] for v in by.values()) / sum(v[1] for v in by.values()) / 1e12:.1f} TF")
+            for k, (cnt, tt_, ff) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+                log(f"{label} {k}: {cnt // NP:4d}/step  {tt_ / cnt * 1e6:8.1f} us  {ff / tt_ / 1e12:7.1f} TF  {tt_ / NP * 1e3:7.2f} ms/step")
+
         NP = 2
+        want_table = bool(os.environ.get("THEIA_BENCH_GEMM_TABLE")) and rank == 0
         recs = measure(NP)  # same regime as the timed steps (weight-gradient kernels overlap on the side stream)
         tot_by_var = {}
         for t_, _f, v_, _s in recs:
             tot_by_var[v_] = tot_by_var.get(v_, 0.0) + t_
         dom_var = max(tot_by_var, key=tot_by_var.get)  # the tile variant with the largest share of the step
         dom = [(t_, f_) for t_, f_, v_, _s in recs if v_ == dom_var]
-        if os.environ.get("THEIA_BENCH_GEMM_TABLE") and rank == 0:  # per-shape table on stderr (tuning aid)
-            by = {}
-            for t_, fl, var, shp in recs:
-                d = by.setdefault((var,) + shp, [0, 0.0, 0.0])
-                d[0] += 1
-                d[1] += t_
-                d[2] += fl
-            for k, (cnt, tt, ff) in sorted(by.items(), key=lambda kv: -kv[1][1]):
-                log(f"gemm_nt {k}: {cnt // NP:4d}/step  {tt / cnt * 1e6:8.1f} us  {ff / tt / 1e12:7.1f} TF  {tt / NP * 1e3:7.2f} ms/step")
+        if want_table:
+            table("gemm_nt", recs, NP)
         tsum, fsum = sum(t for t, _ in dom), sum(f for _, f in dom)
         achieved = fsum / tsum / 1e12
         # the same launches with the side stream switched off: the kernel alone on the chip
@@ -231,54 +457,59 @@ def main():
             sq.join()
             torch.cuda.synchronize()
             sq.enabled = False
-            if os.environ.get("THEIA_BENCH_GEMM_TABLE") and rank == 0:
+            if want_table:
                 ops.WGRAD_PROFILE = []
             iso_recs = measure(NP)
             iso = [(t_, f_) for t_, f_, v_, _s in iso_recs if v_ == dom_var]
             if ops.WGRAD_PROFILE is not None:  # isolated per-shape tables (tuning aid)
                 wrecs, ops.WGRAD_PROFILE = ops.WGRAD_PROFILE, None
-                for label, rr in (("gemm_nt(isolated)", iso_recs),
-                                  ("gemm_wgrad(isolated)", [(e0.elapsed_time(e1) * 1e-3, fl, var, shp) for (e0, e1, fl, var, shp) in wrecs])):
-                    by = {}
-                    for t_, fl, var, shp in rr:
-                        d = by.setdefault((var,) + shp, [0, 0.0, 0.0])
-                        d[0] += 1
-                        d[1] += t_
-                        d[2] += fl
-                    log(f"{label}: total {sum(v[1] for v in by.values()) / NP * 1e3:.2f} ms/step, {sum(v[2] for v in by.values()) / sum(v[1] for v in by.values()) / 1e12:.1f} TF")
-                    for k, (cnt, tt, ff) in sorted(by.items(), key=lambda kv: -kv[1][1]):
-                        log(f"{label} {k}: {cnt // NP:4d}/step  {tt / cnt * 1e6:8.1f} us  {ff / tt / 1e12:7.1f} TF  {tt / NP * 1e3:7.2f} ms/step")
+                table("gemm_nt(isolated)", iso_recs, NP)
+                table("gemm_wgrad(isolated)", [(e0.elapsed_time(e1) * 1e-3, fl, var, shp) for (e0, e1, fl, var, shp) in wrecs], NP)
             sq.enabled = True
             iso_tf = sum(f for _, f in iso) / sum(t for t, _ in iso) / 1e12
         else:
             iso_tf = achieved
         kname = (f"gemm_nt_pp_kernel<{pfx}> (theia_gemm_nt, 256x256 ping-pong tile)" if dom_var == "256x256"
                  else f"gemm_nt_kernel<{pfx},{dom_var.replace('x', ',')}> (theia_gemm_nt)")
-        # HBM-side bytes per launch of this kernel: PMC numbers cannot be collected inside a timed run, so they come from the
-        # committed summary of tools/pmc_bench_traffic.sh (FETCH_SIZE x2 per the guide's gfx950 correction + WRITE_SIZE,
-        # mean over the launches of the same bench step); null when the file is absent
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic.json")
-        if dom_var == "256x256" and os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = [k for k in tj if k.startswith("gemm_nt_pp_kernel") and (("bf16" in k) == (pfx == "bf16"))]
-                traffic = tj[key[0]]["hbm_bytes_per_launch"] if key else None
-            except Exception:  # a malformed summary must not break the benchmark
-                traffic = None
+        traffic, traffic_src = load_traffic(pfx) if dom_var == "256x256" else (None, None)
         roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK / 1e12,
-                    "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4), "traffic": traffic,
+                    "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": len(dom) // NP, "avg_launch_us": round(tsum / len(dom) * 1e6, 1),
                     "flops_per_launch": round(fsum / len(dom)),
                     "achieved_isolated": round(iso_tf, 1), "frac_isolated": round(iso_tf * 1e12 / MFMA_BF16_PEAK, 4),
                     "note": "achieved/avg_launch_us are measured in the regime of the timed steps (weight-gradient kernels run "
                             "concurrently on a side stream and share the CUs); *_isolated = same launches with that overlap off"}
+        # the student alone: backbone forward + backward (weight gradients on the side stream as in the full step)
+        if args.backbone == BACKBONE:
+            dz = torch.randn(b, 197, 768, device=dev).to(model.engine.dtype) * 1e-3
+
+            def student_step():
+                opt.zero_grad(set_to_none=True)
+                z = model.backbone(images)
+                z.backward(dz)
+
+            for _ in range(2):
+                student_step()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            NS = 5
+            e0.record()
+            for _ in range(NS):
+                student_step()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / NS
+            tf = FLOPS_PER_IMAGE_STUDENT * b / (ms * 1e-3) / 1e12
+            student = {"bound": "mfma", "what": "DeiT-base student alone: patch-embed + 12 layers + final LN, forward + backward "
+                                               "(data and weight gradients), per-GPU batch %d" % b,
+                       "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(tf * 1e12 / MFMA_BF16_PEAK, 4),
+                       "ms": round(ms, 3), "flops_per_image": FLOPS_PER_IMAGE_STUDENT}
 
     if rank == 0:
         imgs = world * b * args.steps
         value = imgs / dt
         out = {
-            "metric": "images/sec train-step (fwd+bwd+allreduce) DeiT-base 5-teacher",
+            "metric": METRIC,
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
@@ -288,18 +519,26 @@ def main():
                        "global_batch": b * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
             "settle_steps": settle_steps,
             "host_enqueue_ms_per_step": round(host_dt * 1e3, 3),
+            "rccl_ranks": rccl_ranks,
+            "selfcheck": checks if checks else "skipped (--no-selfcheck): unchecked run",
             "model_flops_utilization": round(value / world * FLOPS_PER_IMAGE_FWD_BWD / MFMA_BF16_PEAK, 4)
             if args.backbone == BACKBONE else None,
         }
         if roofline is not None:
             out["roofline"] = roofline
+        if student is not None:
+            out["student_roofline"] = student
         if world == 1 and not args.no_cpu_baseline:
-            log("cpu baseline (oracle on host cores) ...")
-            out["cpu_baseline"] = cpu_baseline(args.backbone, TEACHERS)
+            log("cpu baseline (oracle on host cores, BASELINE configs[0] protocol) ...")
+            out["cpu_baseline"] = cpu_baseline(cpu_extra)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def forward_feature_main(args, rank, world, dev):
+    raise SystemExit("--mode forward_feature: see theia_amd/streaming.py (not wired yet)")
 
 
 if __name__ == "__main__":

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define THEIA_ABI_VERSION 2
+#define THEIA_ABI_VERSION 3
 
 enum { THEIA_OK = 0, THEIA_ERR_INVALID = -1, THEIA_ERR_LAUNCH = -2, THEIA_ERR_UNSUPPORTED = -3 };
 enum { THEIA_F32 = 0, THEIA_BF16 = 1 };
@@ -99,10 +99,16 @@ typedef struct theia_gemm_args {
     int32_t ldo;
     int32_t act;
     theia_rowmap_t map;
+    /* tile request: 0 = let the launcher choose (theia_gemm_nt_tile); 128128 / 128064 = the 2-stage kernel with that tile;
+     * 256256 = the 256x256 ping-pong kernel -- THEIA_ERR_UNSUPPORTED if the problem does not meet its requirements
+     * (K % 32 == 0 for bf16 / % 16 for f32, one tap's row <= 16 KiB), so a successful forced call proves which kernel ran
+     * (the parity tests force every tile on small shapes; bench.py cross-checks the automatic choice against a forced one). */
+    int32_t tile;
+    int32_t reserved;
 } theia_gemm_args_t;
 
 int theia_gemm_nt(const theia_gemm_args_t* args, int dtype, void* stream);
-/* tile the launcher picks for an (M, N) problem: BM*1000 + BN (128128, 128064 or 256256) -- for profiling tools */
+/* tile the launcher picks for an (M, N) problem when args->tile == 0: BM*1000 + BN (128128, 128064 or 256256) */
 int theia_gemm_nt_tile(int M, int N, int dtype);
 
 /*

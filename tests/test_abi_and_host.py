@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/theia_hip.h but not exported"
     assert sorted(N.EXPORTED_SYMBOLS) == declared, "ctypes signature table and header disagree"
-    assert lib.theia_abi_version() == 2
+    assert lib.theia_abi_version() == N.ABI_VERSION == 3
     assert lib.theia_dtype_size(N.F32) == 4 and lib.theia_dtype_size(N.BF16) == 2 and lib.theia_dtype_size(7) == -1
 
 
@@ -34,7 +34,8 @@ def test_struct_layout_matches_header():
     # theia_rowmap_t: 1 + 27 + 2 + 2 + 2 + 1 + 5 int32 = 40 int32 (160 B) then 4 int64
     assert C.sizeof(N.RowMap) == 160 + 32
     assert N.RowMap.in_batch_stride.offset == 160
-    assert C.sizeof(N.GemmArgs) == 8 * 8 + 4 * 7 + 4 + C.sizeof(N.RowMap)  # 8 pointers, 7 int32 + pad, map
+    assert C.sizeof(N.GemmArgs) == 8 * 8 + 4 * 7 + 4 + C.sizeof(N.RowMap) + 8  # 8 pointers, 7 int32 + pad, map, tile + reserved
+    assert N.GemmArgs.tile.offset == 8 * 8 + 4 * 7 + 4 + C.sizeof(N.RowMap)
 
 
 def test_host_side_planning_functions():
@@ -65,6 +66,21 @@ def test_host_side_planning_functions():
     w.map.in_c = 64
     assert lib.theia_wgrad_fuses_bias(w, N.BF16) == 0
     assert lib.theia_gemm_nt_tile(25216, 768, N.BF16) == 256256 and lib.theia_gemm_nt_tile(100, 64, N.BF16) in (128064, 128128)
+
+
+def test_every_bench_size_gemm_dispatches_the_pingpong_tile():
+    """The (M, N) of every theia_gemm_nt launch of the default bench step (DeiT-base + cddsv, per-GPU batch 128; table in
+    profiles/*_gemm_shapes_isolated.txt) -> 256x256 (the kernel the forced-tile parity tests cover), except the 32-channel
+    Depth-Anything head Linear, which takes the 128x64 tile."""
+    from theia_amd import _native as N
+    lib = N.lib()
+    b = 128
+    shapes = [(b * 197, 768), (b * 197, 2304), (b * 197, 3072), (b * 196, 768), (b * 256, 768), (b * 256, 1024), (b * 256, 1280),
+              (b * 961, 768), (b * 1024, 768), (b * 240, 768), (b * 225, 768), (b * 4096, 768), (b * 4096, 256)]
+    for M, Nn in shapes:
+        assert lib.theia_gemm_nt_tile(M, Nn, N.BF16) == 256256, (M, Nn)
+    assert lib.theia_gemm_nt_tile(b * 4096, 32, N.BF16) == 128064
+    assert lib.theia_gemm_nt_tile(b * 197, 768, N.F32) == 128128  # the exact-f32 mode stays on the 2-stage kernel
 
 
 def test_resize_plan_tables_are_consistent():

@@ -85,3 +85,88 @@ def test_train_script_synthetic_loss_decreases_and_checkpoint_roundtrip(tmp_path
     m.load_pretrained_weights(os.path.join(tmp_path, ck[0]))
     changed = sum(int(not torch.equal(before[k], v)) for k, v in m.state_dict().items())
     assert changed > 100
+
+
+def test_fused_adamw_leaves_frozen_parameters_alone():
+    """requires_grad=False inside a bucket (frozen embeddings): no gradient, no Adam update, no weight decay -- the same
+    parameters after three steps as torch.optim.AdamW with the same parameters frozen."""
+    from theia_amd.optimizers import FusedAdamW, param_groups_weight_decay
+    ma, teachers = _build()
+    mb, _ = _build()
+    frozen = ("backbone.model.embeddings.position_embeddings", "backbone.model.embeddings.patch_embeddings.projection.weight",
+              "backbone.model.layers.5.mlp.fc1.weight", "backbone.model.layers.5.mlp.fc1.bias", "backbone.model.layers.7.layernorm_after.weight")
+    for m in (ma, mb):
+        for k, p in m.named_parameters():
+            if k in frozen:
+                p.requires_grad = False
+    before = {k: p.detach().clone() for k, p in ma.named_parameters()}
+    images = O.synth_images(2, 0)
+    targets = {t: v.to("cuda:0") for t, v in O.synth_targets(2, teachers, 1).items()}
+    oa = FusedAdamW(ma, lr=1e-3, weight_decay=0.1)
+    ob = torch.optim.AdamW(param_groups_weight_decay(mb, 0.1), lr=1e-3, betas=(0.9, 0.999))
+    for _ in range(3):
+        for m, o in ((ma, oa), (mb, ob)):
+            o.zero_grad()
+            losses = m.get_loss(m(images), targets, as_float=False)
+            (0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]).backward()
+            o.step()
+    pb = dict(mb.named_parameters())
+    for k, p in ma.named_parameters():
+        if k in frozen:
+            assert p.grad is None and torch.equal(p, before[k]), k
+        elif "k_proj.bias" not in k:
+            assert torch.allclose(p, pb[k], rtol=2e-3, atol=2e-5), k
+
+
+def test_reference_lr_schedulers_drive_fused_adamw():
+    """FusedAdamW is a torch.optim.Optimizer: both reference schedules (lr_schedulers.py:8-77) produce the same LR sequence
+    on it as on torch.optim.AdamW -- in particular the cosine one is not silently replaced by a constant."""
+    from theia_amd.lr_schedulers import get_constant_lrs_with_linear_warm_up, get_cos_lrs_with_linear_warm_up
+    from theia_amd.optimizers import FusedAdamW
+    ma, _ = _build()
+    for make, kw in ((get_constant_lrs_with_linear_warm_up, {}), (get_cos_lrs_with_linear_warm_up, {"cos_lrs_T_0": 6})):
+        oa = FusedAdamW(ma, lr=2e-3)
+        ob = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(4))], lr=2e-3)
+        sa, sb = make(oa, warm_up_steps=4, warm_up_lr_start_factor=1e-2, **kw), make(ob, warm_up_steps=4, warm_up_lr_start_factor=1e-2, **kw)
+        la, lb = [], []
+        for _ in range(14):
+            oa.step()  # no gradients: a no-op update, the schedule only needs the call order
+            ob.step()
+            sa.step()
+            sb.step()
+            la.append(oa.param_groups[0]["lr"])
+            lb.append(ob.param_groups[0]["lr"])
+        assert la == pytest.approx(lb, rel=1e-12)
+        if kw:
+            assert min(la[4:]) < 0.5 * max(la[4:])  # the cosine actually anneals
+
+
+def test_train_script_with_cosine_schedule(tmp_path):
+    from theia_amd.scripts.train import train_rvfm
+    hist = train_rvfm.main([
+        "dataset=synthetic", "training/target_models=dinov2", "model.backbone.backbone=facebook/deit-tiny-patch16-224",
+        "training.batch_size=4", "training.epochs=1", "dataset.train_steps_per_epoch=10", "dataset.eval_steps_per_epoch=1",
+        "training.base_lr=2e-2", "+dataset.fixed_batch=true", "precision=bf16", f"logging.model_path={tmp_path}", "+logging.log_interval=5",
+        "training.lr_scheduler._target_=theia.lr_schedulers.get_cos_lrs_with_linear_warm_up",
+    ])
+    tl = [v for _, v in hist["train_main_loss"]]
+    assert len(tl) == 2 and all(v == v for v in tl)
+
+
+def test_feature_ingest_ring_survives_the_host_running_ahead():
+    """The host stages batch N+1 while batch N's H2D copy may still be queued (the training loop does not synchronise per
+    step): every returned batch must still hold ITS values.  A long kernel on the compute stream keeps the GPU behind."""
+    from theia_amd.dataset import FeatureIngest
+    dev = torch.device("cuda:0")
+    ing = FeatureIngest(dev)
+    C, H, b = 1024, 16, 16
+    busy = torch.empty(64 << 20, device=dev)
+    outs = []
+    for i in range(6):
+        for _ in range(8):
+            busy.normal_()  # queue work so that the host is well ahead of the device
+        x = torch.full((b, C, H, H), float(i + 1)).to(torch.bfloat16)
+        outs.append((i, ing({"t": x})["t"]))
+    torch.cuda.synchronize()
+    for i, o in outs:
+        assert float(o.min()) == float(o.max()) == float(i + 1), i

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtheia_hip.so")
 
 F32, BF16 = 0, 1
+ABI_VERSION = 3
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_MUL_DGELU, ACT_MUL_DRELU = 0, 1, 2, 3, 4
 MAX_TAPS = 9
 
@@ -44,6 +45,7 @@ class GemmArgs(C.Structure):
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("ldw", C.c_int32), ("ldo", C.c_int32), ("act", C.c_int32),
         ("map", RowMap),
+        ("tile", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -139,7 +141,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if handle.theia_abi_version() != 2:
+        if handle.theia_abi_version() != ABI_VERSION:
             raise TheiaNativeError("libtheia_hip.so ABI version mismatch")
         _lib = handle
     return _lib

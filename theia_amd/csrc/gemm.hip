@@ -288,16 +288,23 @@ extern "C" int theia_gemm_nt(const theia_gemm_args_t* a, int dtype, void* stream
     int rc = check_rowmap(a->map, dtype == THEIA_BF16 ? 64 : 32, "theia_gemm_nt");
     if (rc) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int tile = theia_gemm_nt_tile(a->M, a->N, dtype);
+    THEIA_CHECK_ARG(a->tile == 0 || a->tile == 128128 || a->tile == 128064 || a->tile == 256256, "theia_gemm_nt: bad tile request %d", a->tile);
+    const int tile = a->tile != 0 ? a->tile : theia_gemm_nt_tile(a->M, a->N, dtype);
     // 256x256 tiles run the ping-pong kernel (gemm_pp.hip); THEIA_GEMM_KERNEL=std forces the 2-stage kernel (A/B runs)
     static int use_pp = -1;
     if (use_pp < 0) {
         const char* e = getenv("THEIA_GEMM_KERNEL");
         use_pp = (e != nullptr && strcmp(e, "std") == 0) ? 0 : 1;
     }
-    if (use_pp && tile == 256256 && a->K % (dtype == THEIA_BF16 ? 32 : 16) == 0 &&
-        (int64_t)a->map.in_c * (dtype == THEIA_BF16 ? 2 : 4) <= 16384)  // one tap's row fits the ping-pong kernel's zero page
-        return theia_gemm_nt_pp_launch(a, dtype, s);
+    const int hkt = dtype == THEIA_BF16 ? 32 : 16;  // k elements of one half-tile of the ping-pong kernel
+    const bool pp_ok = a->K % hkt == 0 && a->map.in_c % hkt == 0 &&
+                       (int64_t)a->map.in_c * (dtype == THEIA_BF16 ? 2 : 4) <= 16384;  // one tap's row fits the kernel's zero page
+    if (a->tile == 256256 && !pp_ok) {
+        theia_set_error("theia_gemm_nt: the 256x256 ping-pong kernel needs K and in_c multiples of %d and in_c <= %d (K=%d in_c=%d)", hkt,
+                        dtype == THEIA_BF16 ? 8192 : 4096, a->K, a->map.in_c);
+        return THEIA_ERR_UNSUPPORTED;
+    }
+    if ((use_pp || a->tile == 256256) && tile == 256256 && pp_ok) return theia_gemm_nt_pp_launch(a, dtype, s);
     if (dtype == THEIA_BF16) {
         if (tile == 256256) return launch_gemm_nt<bf16_t, 256, 256, 2, 4>(a, s);
         return tile == 128064 ? launch_gemm_nt<bf16_t, 128, 64, 2, 2>(a, s) : launch_gemm_nt<bf16_t, 128, 128, 2, 2>(a, s);

@@ -50,20 +50,34 @@ class FeatureIngest:
             raise RuntimeError("FeatureIngest runs on a ROCm GPU only (no CPU fallback)")
         self.means = {k: v.to(self.device, torch.float32).contiguous() for k, v in (means or {}).items()}
         self.stds = {k: v.to(self.device, torch.float32).contiguous() for k, v in (stds or {}).items()}
-        self._pinned: Dict[str, torch.Tensor] = {}
+        # Per teacher a ring of pinned staging buffers, each with the event of the H2D copy that last read it: the host runs
+        # steps ahead of the GPU (the training loop only synchronises every log_interval steps), so a buffer may be rewritten
+        # only after ITS copy has completed -- event.synchronize() before the host write; with two buffers that wait is
+        # normally already over.
+        self._ring: Dict[str, List[list]] = {}
+        self._next: Dict[str, int] = {}
         self._copy_stream = torch.cuda.Stream(device=self.device)
+        self.ring_depth = 2
 
-    def _stage(self, key: str, samples: List[torch.Tensor]) -> torch.Tensor:
+    def _stage(self, key: str, samples: List[torch.Tensor]):
         shape = (len(samples),) + tuple(samples[0].shape)
-        buf = self._pinned.get(key)
-        if buf is None or tuple(buf.shape) != shape:
-            buf = torch.empty(shape, dtype=torch.bfloat16).pin_memory()
-            self._pinned[key] = buf
+        ring = self._ring.get(key)
+        if ring is None or tuple(ring[0][0].shape) != shape:
+            for slot in ring or []:
+                if slot[1] is not None:
+                    slot[1].synchronize()
+            ring = [[torch.empty(shape, dtype=torch.bfloat16).pin_memory(), None] for _ in range(self.ring_depth)]
+            self._ring[key], self._next[key] = ring, 0
+        slot = ring[self._next[key]]
+        self._next[key] = (self._next[key] + 1) % len(ring)
+        if slot[1] is not None:
+            slot[1].synchronize()  # the copy that last read this buffer has finished
+        buf = slot[0]
         for i, s in enumerate(samples):
             if s.dtype != torch.bfloat16 or tuple(s.shape) != shape[1:]:
                 raise ValueError(f"{key}: every embedding must be bf16 {shape[1:]}, got {s.dtype} {tuple(s.shape)}")
             buf[i].copy_(s)
-        return buf
+        return slot
 
     def __call__(self, batch: Dict[str, List[torch.Tensor]]) -> Dict[str, torch.Tensor]:
         """batch[teacher] = list of bf16 [C, H, W] host tensors (one per sample) or one bf16 [b, C, H, W] tensor."""
@@ -73,11 +87,15 @@ class FeatureIngest:
             if isinstance(val, torch.Tensor) and val.is_cuda:
                 dev_x = val.contiguous()
             else:
-                host = self._stage(key, list(val) if not isinstance(val, torch.Tensor) else list(val.unbind(0)))
-                self._copy_stream.wait_stream(cur)  # the staging buffer's previous consumer has been enqueued on `cur`
+                slot = self._stage(key, list(val) if not isinstance(val, torch.Tensor) else list(val.unbind(0)))
+                # the copy does not wait for compute already queued on `cur` (the destination is a fresh allocation of the
+                # copy stream): H2D overlaps the previous step's kernels
                 with torch.cuda.stream(self._copy_stream):
-                    dev_x = host.to(self.device, non_blocking=True)
-                cur.wait_stream(self._copy_stream)
+                    dev_x = slot[0].to(self.device, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._copy_stream)
+                slot[1] = ev
+                cur.wait_event(ev)
                 dev_x.record_stream(cur)
             out[key] = ops.feature_ingest_bf16(dev_x, self.means.get(key), self.stds.get(key))
         return out

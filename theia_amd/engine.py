@@ -245,10 +245,14 @@ class StudentEngine:
         return [p for b in self.buckets for p in b.params]
 
     def _grad(self, p: torch.nn.Parameter) -> Tuple[torch.Tensor, bool]:
-        """(view of the flat bucket for p, accumulate?) and makes p.grad that view."""
+        """(view of the flat bucket for p, accumulate?) and makes p.grad that view.  A frozen parameter (requires_grad False)
+        keeps p.grad untouched: the kernel that produces its gradient together with a trainable neighbour's writes into the
+        bucket slot as scratch, and the optimizer skips it."""
         b, i = self._bucket_of[id(p)]
         b.ensure(p.device)
         v = b.view(i)
+        if not p.requires_grad:
+            return v, False
         if p.grad is None:
             p.grad = v
             return v, False
@@ -468,6 +472,8 @@ class StudentEngine:
         # CUs left idle by the tail rounds and epilogues of the data-gradient chain on the main stream (and vice versa)
         def wgrad(dy, x, pw, pb):
             """weight and bias gradient of one nn.Linear: one GEMM launch (+ slab reduce) on the side stream"""
+            if not (pw.requires_grad or pb.requires_grad):
+                return
             gw_, accw_ = self._grad(pw)
             gb_, accb_ = self._grad(pb)
             side.run(lambda: ops.linear_wgrad(dy, x, gw_, accw_, side.ws, bias=(gb_, accb_)), dy, x)

@@ -1,11 +1,17 @@
-"""Fused AdamW over the engine's flat parameter / gradient buckets (one HIP launch per bucket segment).
+"""Fused AdamW over the engine's flat parameter / gradient buckets (one HIP launch per contiguous run of trainable parameters).
 
 Semantics of ``torch.optim.AdamW`` (the reference's optimizer, configs/training/frame_level.yaml:18-20) with the
 reference's decay grouping (optimizers/utils.py:8-35).  Parameters are re-pointed into flat fp32 buffers laid out
-exactly like the gradient buckets ([decay params | no-decay params] per bucket), so a step is 2 launches per bucket."""
+exactly like the gradient buckets ([decay params | no-decay params] per bucket), so a step is 2 launches per bucket when
+every parameter of the bucket is trainable.  Parameters with ``requires_grad=False`` (``freeze_translator``, frozen
+embeddings, ...) or without a gradient are left untouched -- no Adam update, no weight decay -- like torch's optimizer.
+
+It IS a ``torch.optim.Optimizer`` (one param group holding every parameter), so the reference's LR schedulers
+(``theia.lr_schedulers.*``: ``SequentialLR`` of ``LinearLR`` and ``ConstantLR`` / ``CosineAnnealingWarmRestarts``) drive
+``param_groups[0]["lr"]`` exactly as they drive ``torch.optim.AdamW``."""
 from __future__ import annotations
 
-from typing import Optional
+from typing import List, Tuple
 
 import torch
 
@@ -13,14 +19,14 @@ from .. import engine as _engine_mod
 from .. import ops
 
 
-class FusedAdamW:
+class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
         rvfm = model.module if hasattr(model, "module") else model
         self.engine = rvfm.engine
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        params = [p for b in self.engine.buckets for p in b.params]
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.step_count = 0
-        self.param_groups = [{"lr": lr}]  # lets torch LR schedulers drive `lr`
-        self.state = []
+        self.flat_state = []
         for b in self.engine.buckets:
             dev = b.params[0].device
             if dev.type != "cuda":
@@ -30,8 +36,13 @@ class FusedAdamW:
                 v = pflat[b.offsets[i]:b.offsets[i] + p.numel()].view(p.shape)
                 v.copy_(p.data)
                 p.data = v
-            self.state.append({"p": pflat, "m": torch.zeros_like(pflat), "v": torch.zeros_like(pflat)})
+            self.flat_state.append({"p": pflat, "m": torch.zeros_like(pflat), "v": torch.zeros_like(pflat)})
         _engine_mod.PARAM_EPOCH[0] += 1
+
+    # convenience mirrors of the single param group
+    @property
+    def lr(self) -> float:
+        return self.param_groups[0]["lr"]
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         for b in self.engine.buckets:
@@ -41,18 +52,53 @@ class FusedAdamW:
                 elif p.grad is not None:
                     ops.fill_zero(p.grad)
 
-    def step(self) -> None:
+    @staticmethod
+    def _runs(bucket, lo: int, hi: int) -> List[Tuple[int, int]]:
+        """[start, end) element ranges of the flat bucket covering maximal runs of consecutive parameters lo..hi-1 that are
+        trainable and have a gradient living in the bucket"""
+        runs: List[Tuple[int, int]] = []
+        cur = None
+        for i in range(lo, hi):
+            p = bucket.params[i]
+            s_i = bucket.offsets[i]
+            e_i = bucket.offsets[i + 1] if i + 1 < len(bucket.params) else bucket.numel  # includes the alignment padding (zeros)
+            live = p.requires_grad and p.grad is not None
+            if live and p.grad.data_ptr() != bucket.flat.data_ptr() + 4 * s_i:
+                bucket.view(i).copy_(p.grad)  # a foreign .grad tensor (set by user code): bring it into the bucket
+            if live:
+                cur = [s_i, e_i] if cur is None else [cur[0], e_i]
+            elif cur is not None:
+                runs.append((cur[0], cur[1]))
+                cur = None
+        if cur is not None:
+            runs.append((cur[0], cur[1]))
+        return runs
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
         self.step_count += 1
-        lr = self.param_groups[0]["lr"]
-        b1, b2 = self.betas
-        for b, st in zip(self.engine.buckets, self.state):
-            if b.flat is None or not any(p.requires_grad and p.grad is not None for p in b.params):
+        g = self.param_groups[0]
+        lr, (b1, b2), eps, wd = g["lr"], g["betas"], g["eps"], g["weight_decay"]
+        for b, st in zip(self.engine.buckets, self.flat_state):
+            if b.flat is None:
                 continue
-            n_decay = b.decay_numel
-            if n_decay > 0:
-                ops.adamw_step(st["p"][:n_decay], b.flat[:n_decay], st["m"][:n_decay], st["v"][:n_decay], lr, b1, b2, self.eps,
-                               self.weight_decay, self.step_count)
-            if b.numel > n_decay:
-                ops.adamw_step(st["p"][n_decay:], b.flat[n_decay:], st["m"][n_decay:], st["v"][n_decay:], lr, b1, b2, self.eps, 0.0,
-                               self.step_count)
+            n_dec = sum(1 for i in range(len(b.params)) if b.offsets[i] < b.decay_numel)
+            for lo, hi, decay in ((0, n_dec, wd), (n_dec, len(b.params), 0.0)):
+                for s, e in self._runs(b, lo, hi):
+                    ops.adamw_step(st["p"][s:e], b.flat[s:e], st["m"][s:e], st["v"][s:e], lr, b1, b2, eps, decay, self.step_count)
         _engine_mod.PARAM_EPOCH[0] += 1
+        return loss
+
+    # checkpointing: flat moments + step counter (the per-parameter ``state`` dict of torch optimizers is not used)
+    def state_dict(self):
+        return {"step_count": self.step_count, "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
+                "m": [st["m"].clone() for st in self.flat_state], "v": [st["v"].clone() for st in self.flat_state]}
+
+    def load_state_dict(self, sd) -> None:
+        self.step_count = int(sd["step_count"])
+        for g, sg in zip(self.param_groups, sd["param_groups"]):
+            g.update(sg)
+        for st, m, v in zip(self.flat_state, sd["m"], sd["v"]):
+            st["m"].copy_(m)
+            st["v"].copy_(v)

@@ -210,17 +210,19 @@ def ddp_main(cfg) -> dict:
 
     lr = cfg.training.base_lr * ((cfg.training.batch_size * world_size) / (cfg.training.base_batch_size * cfg.training.base_world_size))
     if cfg.training.optimizer.get("_target_", "") in ("torch.optim.AdamW", "theia_amd.optimizers.FusedAdamW") and not cfg.training.grad_clip:
-        # same update rule as torch.optim.AdamW, fused over the engine's flat buckets (2 HIP launches per bucket)
+        # same update rule as torch.optim.AdamW, fused over the engine's flat buckets (2 HIP launches per bucket); it is a
+        # torch.optim.Optimizer, so the configured LR scheduler (constant or cosine warm restarts, both behind a linear
+        # warm-up: lr_schedulers.py:8-77) drives it exactly as in the reference
         optimizer = FusedAdamW(rvfm_ddp, lr=lr, betas=tuple(cfg.training.optimizer.get("betas", (0.9, 0.999))),
                                weight_decay=cfg.training.weight_decay)
-        lr_scheduler = _HostLR(optimizer, int(cfg.training.warm_up_steps_ratio * total_train_steps),
-                               cfg.training.lr_scheduler.get("warm_up_lr_start_factor", 1e-2))
     else:
         groups = param_groups_weight_decay(rvfm_ddp, cfg.training.weight_decay)
         optimizer = cfglib.instantiate(cfg.training.optimizer, groups, lr=lr)
-        lr_scheduler = cfglib.instantiate(cfg.training.lr_scheduler, optimizer=optimizer,
-                                          warm_up_steps=int(cfg.training.warm_up_steps_ratio * total_train_steps),
-                                          cos_lrs_T_0=int(total_train_steps * (1 - cfg.training.warm_up_steps_ratio)))
+    warm_up_steps = int(cfg.training.warm_up_steps_ratio * total_train_steps)
+    sched_kwargs = dict(optimizer=optimizer, warm_up_steps=warm_up_steps)
+    if "get_cos_lrs" in cfg.training.lr_scheduler.get("_target_", ""):
+        sched_kwargs["cos_lrs_T_0"] = int(total_train_steps * (1 - cfg.training.warm_up_steps_ratio))
+    lr_scheduler = cfglib.instantiate(cfg.training.lr_scheduler, **sched_kwargs)
     if rank == 0:
         print(cfglib.to_yaml(cfg), flush=True)
     history = train(rvfm_ddp, target_model_names, optimizer, lr_scheduler, train_iter, eval_iter, cfg=cfg, device=local_rank,
@@ -228,22 +230,6 @@ def ddp_main(cfg) -> dict:
                     warmup_steps=int(cfg.training.warm_up_steps_ratio * total_train_steps))
     ddp_cleanup()
     return history
-
-
-class _HostLR:
-    """Linear warm-up -> constant (reference default schedule, lr_schedulers.py:41-77) for FusedAdamW."""
-
-    def __init__(self, opt: FusedAdamW, warm_up_steps: int, start_factor: float):
-        self.opt, self.n, self.f0, self.base, self.k = opt, max(1, warm_up_steps), start_factor, opt.param_groups[0]["lr"], 0
-        self._apply()
-
-    def _apply(self) -> None:
-        f = self.f0 + (1.0 - self.f0) * min(1.0, self.k / self.n)
-        self.opt.param_groups[0]["lr"] = self.base * f
-
-    def step(self) -> None:
-        self.k += 1
-        self._apply()
 
 
 def main(argv=None) -> dict:

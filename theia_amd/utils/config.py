@@ -11,9 +11,25 @@ from __future__ import annotations
 
 import copy
 import os
+import re
 from typing import Any, Dict, List
 
 import yaml
+
+# PyYAML implements YAML 1.1, whose float needs a dot: "2e-3" / "1e-2" (the notation of the reference's own
+# configs/training/frame_level.yaml, and of README-style overrides) load as STRINGS.  Hydra/OmegaConf read them as floats.
+_EXP_FLOAT = re.compile(r"^[+-]?(\d+\.?\d*|\.\d+)[eE][+-]?\d+$")
+
+
+def _coerce(x):
+    """exponent-notation strings -> float, recursively through dicts and lists"""
+    if isinstance(x, str) and _EXP_FLOAT.match(x.strip()):
+        return float(x)
+    if isinstance(x, dict):
+        return {k: _coerce(v) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_coerce(v) for v in x]
+    return x
 
 _TEACHER_SETS = {
     "dinov2": ["facebook/dinov2-large"],
@@ -84,7 +100,7 @@ def _load_group(group: str, option: str, config_path: str | None) -> Dict[str, A
     if config_path:
         f = os.path.join(config_path, group, option + ".yaml")
         if os.path.exists(f):
-            d = yaml.safe_load(open(f)) or {}
+            d = _coerce(yaml.safe_load(open(f)) or {})
             dd = {k: v for k, v in d.items() if k != "defaults"}
             nested = {}
             for item in d.get("defaults", []) or []:
@@ -115,7 +131,7 @@ def _place(root: Dict[str, Any], group: str, value: Dict[str, Any]) -> None:
 
 def _parse_value(s: str):
     try:
-        return yaml.safe_load(s)
+        return _coerce(yaml.safe_load(s))
     except yaml.YAMLError:
         return s
 
