@@ -114,6 +114,17 @@ class RobotVisionFM(nn.Module):
         return handle_feature_output(feature, feature_reduce_method=self.feature_reduce_method,
                                      num_discard_tokens=self.num_reg_tokens)
 
+    def forward_feature_streamed(self, x: torch.Tensor, chunk: int = 512, out: Optional[torch.Tensor] = None, **kwargs: Any) -> torch.Tensor:
+        """``forward_feature`` for a large uint8 batch (device-resident or pinned host memory) that is streamed through ONE
+        hipGraph capture of the forward of ``chunk`` images (theia_amd/streaming.py): same values as ``forward_feature``, one
+        host call per chunk.  Inference only (no autograd graph)."""
+        from ..streaming import StreamedForwardFeature
+        key = (int(chunk), tuple(sorted(kwargs.items())))
+        sff = self.__dict__.setdefault("_streamers", {}).get(key)
+        if sff is None:
+            sff = self.__dict__["_streamers"][key] = StreamedForwardFeature(self, chunk, **kwargs)
+        return sff(x, out=out)
+
     def forward(self, x: Any, target_model_names: Optional[list] = None, **kwargs: Any) -> dict:
         x = self.backbone(x, **kwargs)
         if self.num_reg_tokens > 0:  # pragma: no cover - DeiT has none
