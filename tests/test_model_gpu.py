@@ -94,9 +94,14 @@ def test_fp32_matches_reference_goldens(golden_dir, key):
         worst = max(worst, r)
         assert r < 1e-3, (k, gn, gn_ref[i])
         gv = gr.detach().float().cpu().numpy().reshape(-1)[g["gradidx_cos_l1"][i]]
-        # sampled gradient values: within 1 % of the tensor's RMS gradient (measured worst case: 0.3 % on the patch-embedding
-        # weight of DeiT-base, the end of the 12-layer backward chain; the norm check above is the 1e-3 gate)
-        assert np.abs(gv - g["gradval_cos_l1"][i]).max() <= 1e-2 * gn_ref[i] / np.sqrt(gr.numel()) + 1e-9, k
+        # 4 sampled gradient values per tensor, error in units of the tensor's RMS gradient.  Tight level 3e-3 (measured worst
+        # case of pure f32 summation-order noise: 3e-3 on DeiT-base's patch-embedding weight, the end of the 12-layer backward
+        # chain).  ONE of the four may sit at the loose level 3e-2: a ReLU pre-activation of the translator heads within ~1e-7
+        # of zero takes the other branch under a different f32 summation order (~0.3 such units per 3M-element map), which
+        # moves the few gradient entries fed by that unit by ~1/sqrt(9C) of their RMS (seen: 1.4e-2 on one LN-affine entry of
+        # golden G5) -- a discontinuity of the function, not of the kernels.  The norm check above is the 1e-3 gate.
+        errs = np.sort(np.abs(gv - g["gradval_cos_l1"][i]) / (gn_ref[i] / np.sqrt(gr.numel()) + 1e-30))
+        assert errs[-1] <= 3e-2 and errs[-2] <= 3e-3, (k, errs)
     print(f"[{key}] worst grad-norm rel err {worst:.2e}")
 
 
