@@ -100,9 +100,12 @@ typedef struct theia_gemm_args {
     int32_t act;
     theia_rowmap_t map;
     /* tile request: 0 = let the launcher choose (theia_gemm_nt_tile); 128128 / 128064 = the 2-stage kernel with that tile;
-     * 256256 = the 256x256 ping-pong kernel -- THEIA_ERR_UNSUPPORTED if the problem does not meet its requirements
-     * (K % 32 == 0 for bf16 / % 16 for f32, one tap's row <= 16 KiB), so a successful forced call proves which kernel ran
-     * (the parity tests force every tile on small shapes; bench.py cross-checks the automatic choice against a forced one). */
+     * 256256 = the 256x256 ping-pong kernel; 256009 = the 256x256 ping-pong kernel for 3x3 stride-1 convolutions whose
+     * 256-row tile is one 16x16 output image (the input slice is staged once, the 9 taps read shifted rows of it).
+     * A request the problem does not meet (K % 32 == 0 for bf16 / % 16 for f32, one tap's row <= 16 KiB; 256009: 9 taps on a
+     * full 3x3 grid, stride 1, rows_h = rows_w = 16, M % 256 == 0) is THEIA_ERR_UNSUPPORTED, never a fall-back, so a
+     * successful forced call proves which kernel ran (the parity tests force every kernel on small shapes; bench.py
+     * cross-checks the automatic choice against a forced one). */
     int32_t tile;
     int32_t reserved;
 } theia_gemm_args_t;
@@ -110,6 +113,9 @@ typedef struct theia_gemm_args {
 int theia_gemm_nt(const theia_gemm_args_t* args, int dtype, void* stream);
 /* tile the launcher picks for an (M, N) problem when args->tile == 0: BM*1000 + BN (128128, 128064 or 256256) */
 int theia_gemm_nt_tile(int M, int N, int dtype);
+/* the kernel theia_gemm_nt would run for these arguments (no launch): 128128 / 128064 / 256000 (2-stage kernel, that tile),
+ * 256256 (ping-pong), 256009 (ping-pong, 3x3 convolution with one image per tile); negative on a refused request */
+int theia_gemm_nt_plan(const theia_gemm_args_t* args, int dtype);
 
 /*
  * Weight gradient:  slab[s][n][wslot[t]*in_c + ci] = sum_{m in split s} dY[m, n] * A[m, (t, ci)]

@@ -163,7 +163,8 @@ def _pack(plan_pack, w, dt, dev):
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("kind", ["conv_p1", "convT_s1", "convT_s2_p1", "convT_s2_op1"])
 @pytest.mark.parametrize("C", [64, 256])  # in_c % 256 == 0 is what the ping-pong WEIGHT-GRADIENT kernel needs
-@pytest.mark.parametrize("tile", TILES)    # forward / data-gradient GEMMs: library's choice, 2-stage 128x128, 256x256 ping-pong
+@pytest.mark.parametrize("tile", TILES + [256009])  # forward / data-gradient GEMMs: library's choice, 2-stage 128x128, 256x256
+# ping-pong, and the one-image-per-tile convolution kernel (256009: the row maps it takes -- 16x16 output, stride 1, 3x3)
 def test_conv_family_fwd_dgrad_wgrad(dt, kind, C, tile):
     """Implicit-GEMM convolutions vs the oracle's shifted-matmul restatement (itself pinned to torch by G10)."""
     from theia_amd import ops, _native as Nn
@@ -194,11 +195,22 @@ def test_conv_family_fwd_dgrad_wgrad(dt, kind, C, tile):
     wdg = _pack(plan.pack_dgrad, W, dt, dev)
     out = torch.empty(b, OH, OH, C, dtype=dt, device=dev)
     out_relu = torch.empty_like(out)
+    conv_kernel_fwd = kind in ("conv_p1", "convT_s1")  # 16x16 outputs of a stride-1 3x3 map
+    conv_kernel_dgrad = kind == "conv_p1"
+    for rmap, mpi in plan.fwd:
+        assert (ops.gemm_nt(xd, wf, out, b * mpi, C, rmap.ntaps * C, rmap, 9 * C, C, tile=256009, plan_only=True) == 256009) == conv_kernel_fwd
+    if tile == 256009 and not conv_kernel_fwd:
+        with pytest.raises(Nn.TheiaNativeError, match="256009"):
+            rmap, mpi = plan.fwd[0]
+            ops.gemm_nt(xd, wf, out, b * mpi, C, rmap.ntaps * C, rmap, 9 * C, C, tile=tile)
+        return
     for rmap, mpi in plan.fwd:
         ops.gemm_nt(xd, wf, out, b * mpi, C, rmap.ntaps * C, rmap, 9 * C, C, bias=bias.to(dev), tile=tile)
         ops.gemm_nt(xd, wf, out_relu, b * mpi, C, rmap.ntaps * C, rmap, 9 * C, C, bias=bias.to(dev), act=Nn.ACT_RELU, tile=tile)
     assert relerr(out.float(), ref.detach()) < TOL[dt]
     assert relerr(out_relu.float(), ref_relu.detach()) < TOL[dt]
+    if tile == 256009 and not conv_kernel_dgrad:
+        return
     # data gradient
     gyd = gy.to(dev, dt)
     dx = torch.empty(b, IH, IH, C, dtype=dt, device=dev)
@@ -226,7 +238,7 @@ def test_conv_family_fwd_dgrad_wgrad(dt, kind, C, tile):
     assert relerr(gb2 - 0.5, gyr.double().sum((0, 1, 2))) < 1e-5
 
 
-@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("tile", TILES + [256009])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_pad_convT_on_strided_tokens(dt, tile):
     """The 14->16 pad reads z[:,1:,:] in place (batch stride 197*C, offset C) and its dgrad writes dz[:,1:,:]."""
@@ -248,6 +260,9 @@ def test_pad_convT_on_strided_tokens(dt, tile):
     dz = torch.zeros(b, 197, C, dtype=dt, device=dev)
     wdg = _pack(plan.pack_dgrad, W, dt, dev)
     rmap, mpi = plan.dgrad
+    if tile == 256009:  # the data-gradient has 14x14 rows per image: not a one-image-per-tile map
+        assert ops.gemm_nt(gy.to(dev, dt), wdg, dz, b * mpi, C, 9 * C, rmap, 9 * C, C, plan_only=True) != 256009
+        return
     ops.gemm_nt(gy.to(dev, dt), wdg, dz, b * mpi, C, 9 * C, rmap, 9 * C, C, tile=tile)
     zz = zr.clone().requires_grad_(True)
     (O.convT3x3(zz[:, 1:].reshape(b, 14, 14, C), Wr, bias, 1, 0, 0) * rnd(gy, dt)).sum().backward()

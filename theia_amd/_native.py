@@ -75,6 +75,7 @@ _SIGNATURES = {
     "theia_dtype_size": (C.c_int, [C.c_int]),
     "theia_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_void_p]),
     "theia_gemm_nt_tile": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "theia_gemm_nt_plan": (C.c_int, [C.POINTER(GemmArgs), C.c_int]),
     "theia_gemm_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_int, C.c_void_p]),
     "theia_wgrad_fuses_bias": (C.c_int, [C.POINTER(WgradArgs), C.c_int]),
     "theia_wgrad_splits": (C.c_int, [C.c_int, C.c_int, C.c_int]),

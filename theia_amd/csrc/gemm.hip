@@ -54,6 +54,9 @@ __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + 
 // NT implicit GEMM
 // ================================================================================================
 int theia_gemm_nt_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t stream);               // gemm_pp.hip
+struct conv_taps_t;
+bool theia_gemm_conv_pp_match(const theia_gemm_args_t* a, int dtype, conv_taps_t* out);                 // gemm_conv_pp.hip
+int theia_gemm_conv_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t stream);
 
 __device__ uint4 g_zero_page[16];  // 256 B of zeros: source of out-of-range operand chunks
 
@@ -269,6 +272,47 @@ extern "C" int theia_gemm_nt_tile(int M, int N, int dtype) {
     return big ? 256256 : 128128;
 }
 
+// Which kernel theia_gemm_nt runs for these arguments: 128128 / 128064 = 2-stage kernel with that tile, 256000 = 2-stage kernel
+// with the 256x256 tile (problems the ping-pong kernels do not take), 256256 = ping-pong kernel, 256009 = ping-pong kernel for
+// 3x3 convolutions with one image per tile (gemm_conv_pp.hip); negative = error.
+static int gemm_nt_plan(const theia_gemm_args_t* a, int dtype) {
+    THEIA_CHECK_ARG(a->tile == 0 || a->tile == 128128 || a->tile == 128064 || a->tile == 256256 || a->tile == 256009,
+                    "theia_gemm_nt: bad tile request %d", a->tile);
+    const int tile = a->tile != 0 ? a->tile : theia_gemm_nt_tile(a->M, a->N, dtype);
+    static int use_pp = -1, use_conv = -1;  // THEIA_GEMM_KERNEL=std / THEIA_CONV_KERNEL=std: A/B switches for timing runs
+    if (use_pp < 0) {
+        const char* e = getenv("THEIA_GEMM_KERNEL");
+        use_pp = (e != nullptr && strcmp(e, "std") == 0) ? 0 : 1;
+        e = getenv("THEIA_CONV_KERNEL");
+        use_conv = (e != nullptr && strcmp(e, "std") == 0) ? 0 : 1;
+    }
+    const int hkt = dtype == THEIA_BF16 ? 32 : 16;  // k elements of one half-tile of the ping-pong kernels
+    const bool pp_ok = a->K % hkt == 0 && a->map.in_c % hkt == 0 &&
+                       (int64_t)a->map.in_c * (dtype == THEIA_BF16 ? 2 : 4) <= 16384;  // one tap's row fits the kernel's zero page
+    const bool conv_ok = theia_gemm_conv_pp_match(a, dtype, nullptr);
+    if (a->tile == 256256 && !pp_ok) {
+        theia_set_error("theia_gemm_nt: the 256x256 ping-pong kernel needs K and in_c multiples of %d and in_c <= %d (K=%d in_c=%d)", hkt,
+                        dtype == THEIA_BF16 ? 8192 : 4096, a->K, a->map.in_c);
+        return THEIA_ERR_UNSUPPORTED;
+    }
+    if (a->tile == 256009 && !conv_ok) {
+        theia_set_error("theia_gemm_nt: tile request 256009 needs a 3x3 stride-1 convolution row map with one 16x16 image per 256-row tile");
+        return THEIA_ERR_UNSUPPORTED;
+    }
+    if (a->tile == 256009) return 256009;
+    if (a->tile == 256256) return 256256;
+    if (tile == 256256) {
+        if (use_pp && use_conv && conv_ok) return 256009;
+        return use_pp && pp_ok ? 256256 : 256000;
+    }
+    return tile;
+}
+
+extern "C" int theia_gemm_nt_plan(const theia_gemm_args_t* a, int dtype) {
+    THEIA_CHECK_ARG(a != nullptr && (dtype == THEIA_F32 || dtype == THEIA_BF16), "theia_gemm_nt_plan: bad arguments");
+    return gemm_nt_plan(a, dtype);
+}
+
 extern "C" int theia_gemm_nt(const theia_gemm_args_t* a, int dtype, void* stream) {
     THEIA_CHECK_ARG(a != nullptr, "theia_gemm_nt: null args");
     THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16, "theia_gemm_nt: bad dtype %d", dtype);
@@ -288,28 +332,15 @@ extern "C" int theia_gemm_nt(const theia_gemm_args_t* a, int dtype, void* stream
     int rc = check_rowmap(a->map, dtype == THEIA_BF16 ? 64 : 32, "theia_gemm_nt");
     if (rc) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    THEIA_CHECK_ARG(a->tile == 0 || a->tile == 128128 || a->tile == 128064 || a->tile == 256256, "theia_gemm_nt: bad tile request %d", a->tile);
-    const int tile = a->tile != 0 ? a->tile : theia_gemm_nt_tile(a->M, a->N, dtype);
-    // 256x256 tiles run the ping-pong kernel (gemm_pp.hip); THEIA_GEMM_KERNEL=std forces the 2-stage kernel (A/B runs)
-    static int use_pp = -1;
-    if (use_pp < 0) {
-        const char* e = getenv("THEIA_GEMM_KERNEL");
-        use_pp = (e != nullptr && strcmp(e, "std") == 0) ? 0 : 1;
-    }
-    const int hkt = dtype == THEIA_BF16 ? 32 : 16;  // k elements of one half-tile of the ping-pong kernel
-    const bool pp_ok = a->K % hkt == 0 && a->map.in_c % hkt == 0 &&
-                       (int64_t)a->map.in_c * (dtype == THEIA_BF16 ? 2 : 4) <= 16384;  // one tap's row fits the kernel's zero page
-    if (a->tile == 256256 && !pp_ok) {
-        theia_set_error("theia_gemm_nt: the 256x256 ping-pong kernel needs K and in_c multiples of %d and in_c <= %d (K=%d in_c=%d)", hkt,
-                        dtype == THEIA_BF16 ? 8192 : 4096, a->K, a->map.in_c);
-        return THEIA_ERR_UNSUPPORTED;
-    }
-    if ((use_pp || a->tile == 256256) && tile == 256256 && pp_ok) return theia_gemm_nt_pp_launch(a, dtype, s);
+    const int plan = gemm_nt_plan(a, dtype);
+    if (plan < 0) return plan;
+    if (plan == 256009) return theia_gemm_conv_pp_launch(a, dtype, s);
+    if (plan == 256256) return theia_gemm_nt_pp_launch(a, dtype, s);
     if (dtype == THEIA_BF16) {
-        if (tile == 256256) return launch_gemm_nt<bf16_t, 256, 256, 2, 4>(a, s);
-        return tile == 128064 ? launch_gemm_nt<bf16_t, 128, 64, 2, 2>(a, s) : launch_gemm_nt<bf16_t, 128, 128, 2, 2>(a, s);
+        if (plan == 256000) return launch_gemm_nt<bf16_t, 256, 256, 2, 4>(a, s);
+        return plan == 128064 ? launch_gemm_nt<bf16_t, 128, 64, 2, 2>(a, s) : launch_gemm_nt<bf16_t, 128, 128, 2, 2>(a, s);
     }
-    return tile == 128064 ? launch_gemm_nt<float, 128, 64, 2, 2>(a, s) : launch_gemm_nt<float, 128, 128, 2, 2>(a, s);
+    return plan == 128064 ? launch_gemm_nt<float, 128, 64, 2, 2>(a, s) : launch_gemm_nt<float, 128, 128, 2, 2>(a, s);
 }
 
 // ================================================================================================

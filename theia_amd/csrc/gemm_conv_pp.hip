@@ -1,0 +1,246 @@
+// Ping-pong implicit GEMM for 3x3 stride-1 (transposed) convolutions whose 256-row M tile IS one 16x16 output image:
+// Conv2d 3x3 p1 on 16x16 maps, its data-gradient, and the 14->16 "pad" ConvTranspose2d of the translator heads
+// (adapter_heads.py:279-290,316-324).  Same output, epilogue and wave layout as gemm_nt_pp_kernel (gemm_pp.hip), different
+// operand stream.
+//
+// The generic kernel gathers the activation operand tap by tap: per 32-channel slice it streams 9 x 16 KB of activations
+// (the same <= 256 input pixels, shifted) plus 9 x 16 KB of weights from L2 into LDS, and that L2 -> LDS stream (~10 TB/s
+// over the chip), not the matrix pipe, bounds it.  Here a slice of the input image is staged ONCE
+// (in_h*in_w pixel rows of 64 B) and the 9 taps read their MFMA fragments at SHIFTED pixel rows: lane (x = lane & 15) of
+// output row y reads pixel (y + dy, x + dx), or a row of zeros when that falls outside the image.  Per slice the stream is
+// 16 KB + 9 x 16 KB instead of 18 x 16 KB, and the fragments of one dx serve its three dy taps (30 + 36 ds_read_b128 per
+// slice and wave instead of 108).
+//
+// Unit u = (slice s, tap r = 3*dxi + dyi), 32 MFMAs per wave -- the role a half k-tile plays in gemm_pp.hip; the two wave
+// groups run one barrier apart and alternate R(u) (fragment reads + LDS-DMA issue) and M(u) (MFMAs).
+//   B ring: NB = 6 weight tiles [256 n][64 B]; R(u) issues the tile of unit u + 5 into slot (u + 5) % 6 = (u - 1) % 6, whose
+//           last readers were the R(u - 1) segments of both groups (closed by lgkmcnt(0) before their barrier).
+//   A ring: 2 image slices; slice s + 1 is issued in R(9 s + 2) into the buffer slice s - 1 was last read from in unit 9 s - 3.
+//   waits : end of R(u): counted s_waitcnt vmcnt(8), or (10) in the five units whose queue holds an image slice's two pieces
+//           behind weight tile u + 1 -> the two pieces of weight tile u + 1 have landed (tiles u + 2 .. u + 5 stay in flight),
+//           then the barrier makes every wave's pieces visible.  Image slice s + 1 sits in the queue right behind weight
+//           tile 9 s + 7; the vmcnt(8) at the end of R(9 s + 7) retires it, two units before its first read in R(9 s + 9).
+#include "gemm_tile.h"
+
+__device__ uint4 g_cv_zero_page[16];  // 256 B of zeros: source of out-of-range rows (never advanced)
+
+struct conv_taps_t {
+    int32_t dy0, dx0;       // smallest tap offsets; taps cover (dy0 + dyi, dx0 + dxi), dyi, dxi in 0..2
+    int32_t wslot[9];       // weight slot of tap r = 3*dxi + dyi
+};
+
+__device__ __forceinline__ int cv_f(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+
+template <typename T>
+__global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args_t p, const conv_taps_t tp) {
+    constexpr int BM = 256, BN = 256, WAVES_N = 4;
+    constexpr int NB = 6, PD = NB - 1;
+    constexpr int HKT = 64 / (int)sizeof(T);    // channels per slice (64-byte rows)
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int WM = 128, WN = 64, FM = 8, FN = 4;
+    constexpr int SRP = 128;                     // rows staged per piece (512 threads x 16 B)
+    constexpr int BTILE = BN * 64, ATILE = BM * 64;
+    constexpr int A_OFF = NB * BTILE, Z_OFF = A_OFF + 2 * ATILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ugroup = uwave >> 2;
+    const theia_rowmap_t& mp = p.map;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile = gt_xcd_remap(blockIdx.x, gridDim.x);
+    const int img = tile / tiles_n;
+    const int m0 = img * BM, n0 = (tile % tiles_n) * BN;
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.a);
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.w);
+    const uint64_t zp = reinterpret_cast<uint64_t>(g_cv_zero_page);
+
+    // zero row of the image tile (read by fragments whose pixel is outside the image)
+    if (tid < 4) reinterpret_cast<uint4*>(smem + Z_OFF)[tid] = make_uint4(0, 0, 0, 0);
+
+    // ---- per-thread LDS-DMA sources: rows st_row and st_row + 128 of an image slice / of a weight tile ----
+    const int st_chunk = tid & 3, st_row = tid >> 2;
+    const int lchunk = st_chunk ^ cv_f(st_row);
+    const int npix = mp.in_h * mp.in_w;
+    uint64_t a_src[2], w_src[2];
+    uint32_t w_live[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pix = st_row + SRP * i;
+        const uint64_t pa = reinterpret_cast<uint64_t>(A + (int64_t)img * mp.in_batch_stride + mp.in_offset + (int64_t)pix * mp.in_c + lchunk * EPC);
+        a_src[i] = pix < npix ? pa : 0;  // 0: the zero page, not advanced with the slice
+        const int n = n0 + st_row + SRP * i;
+        w_live[i] = n < p.N ? 0xffffffffu : 0u;
+        w_src[i] = n < p.N ? reinterpret_cast<uint64_t>(W + (int64_t)n * p.ldw + lchunk * EPC) : zp;
+    }
+    auto issue_b = [&](int slot, int r, int s) {  // weight tile of tap r, slice s
+        const uint32_t off = (uint32_t)((tp.wslot[r] * mp.in_c + s * HKT) * (int)sizeof(T));
+        char* dst = smem + slot * BTILE + uwave * (16 * 64);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint64_t src = w_src[i] + (off & w_live[i]);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + i * (SRP * 64)), 16, 0, 0);
+        }
+    };
+    auto issue_a = [&](int s, int buf) {  // image slice s into image buffer buf
+        const uint64_t off = (uint64_t)s * 64;
+        char* dst = smem + A_OFF + buf * ATILE + uwave * (16 * 64);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint64_t src = a_src[i] != 0 ? a_src[i] + off : zp;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + i * (SRP * 64)), 16, 0, 0);
+        }
+    };
+
+    gt_f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = (gt_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nslice = mp.in_c / HKT;
+    const int nunits = nslice * 9;
+    // ---- prologue: image slice 0, weight tiles 0 .. PD-1 (clamped for very short K: duplicates are never read) ----
+    issue_a(0, 0);
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+        const int uc = min(u, nunits - 1);
+        issue_b(u, uc % 9, uc / 9);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PD - 1)) : "memory");  // image slice 0 and weight tile 0 landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the zero row is written
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ugroup == 1) {  // group 1 runs one barrier behind group 0
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // ---- fragment addressing: lane (x = lane & 15, k-chunk fg) of output row y reads pixel (y + dy, x + dx) ----
+    const int frow = lane & 15, fg = lane >> 4;
+    const int y0 = wm * 8 + tp.dy0;          // first pixel row of this wave's fragment window (10 rows: 8 outputs + 2 halo)
+    const uint32_t zaddr = Z_OFF + fg * 16;
+    int bslot = 0;                           // ring slot of the current unit's weight tile
+    uint4 fb[FN], fa[FM];
+    for (int s = 0; s < nslice; ++s) {
+        const char* abuf = smem + A_OFF + (s & 1) * ATILE;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int dxi = r / 3, dyi = r % 3;
+            // ---------------- R(u): fragment reads + LDS-DMA issue
+            const char* sb = smem + bslot * BTILE;
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const int row = wn * WN + i * 16 + frow;
+                fb[i] = *reinterpret_cast<const uint4*>(sb + row * 64 + ((fg ^ cv_f(row)) << 4));
+            }
+            {
+                // The wave's 8 output rows of tap (dyi, dxi) read pixel rows y0 + dyi .. y0 + dyi + 7, shifted by dx.  Row q of
+                // the 10-row window lives in fa[q % 8]: dyi = 0 loads rows 0..7, dyi = 1 replaces row 0 by row 8, dyi = 2 row 1
+                // by row 9 (10 reads per dx, 8 fragment registers).
+                const int ix = frow + tp.dx0 + dxi;
+                const bool xok = (unsigned)ix < (unsigned)mp.in_w;
+                const int q_lo = dyi == 0 ? 0 : FM + dyi - 1, q_hi = dyi == 0 ? FM : FM + dyi;
+#pragma unroll
+                for (int q = q_lo; q < q_hi; ++q) {
+                    const int iy = y0 + q;
+                    const int row = iy * mp.in_w + ix;
+                    const bool ok = xok && (unsigned)iy < (unsigned)mp.in_h;
+                    const uint32_t off = ok ? (uint32_t)(abuf - smem) + row * 64 + ((fg ^ cv_f(row)) << 4) : zaddr;
+                    fa[q % FM] = *reinterpret_cast<const uint4*>(smem + off);
+                }
+            }
+            {
+                // prefetch: weight tile of unit u + PD (clamped at the tail), image slice s + 1 once per slice
+                int rp = r + PD, sp = s;
+                if (rp >= 9) { rp -= 9; ++sp; }
+                if (sp >= nslice) { sp = nslice - 1; rp = 8; }
+                const int pslot = bslot == 0 ? NB - 1 : bslot - 1;  // (u + PD) % NB
+                issue_b(pslot, rp, sp);
+                // every slice issues exactly one image slice (the last one re-fetches itself into the idle buffer, never
+                // read), so the number of LDS-DMA operations younger than a given weight tile is a compile-time constant
+                if (r == 2) issue_a(min(s + 1, nslice - 1), (s + 1) & 1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // weight tile u + 1 landed: younger than it are tiles u + 2 .. u + 5 (8 operations) and, in the five units after an
+            // image slice was queued (behind tile u_A + 5), that slice's two pieces
+            if (r >= 2 && r <= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PD - 1) + 2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PD - 1)) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- M(u): 32 MFMAs
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+#pragma unroll
+                for (int i = 0; i < FN; ++i) GtMma<T>::run(acc[i][j], fb[i], fa[(j + dyi) % FM]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            bslot = bslot == NB - 1 ? 0 : bslot + 1;
+        }
+    }
+    if (ugroup == 0) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): drain the clamped tail prefetches before LDS is reused
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    float* ep = reinterpret_cast<float*>(smem) + wave * (64 * (WN + 4));
+    gt_epilogue<T, WM, WN>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
+}
+
+// Does the row map describe a convolution this kernel takes?  (one 16x16 output image per 256-row tile, stride 1, taps a
+// full 3x3 grid of consecutive offsets, the input image within 256 pixels)  Fills the tap grid when it does.
+bool theia_gemm_conv_pp_match(const theia_gemm_args_t* a, int dtype, conv_taps_t* out) {
+    const theia_rowmap_t& m = a->map;
+    const int hkt = dtype == THEIA_BF16 ? 32 : 16;
+    if (m.ntaps != 9 || m.rows_h != 16 || m.rows_w != 16 || m.in_sy != 1 || m.in_sx != 1) return false;
+    if (a->M % 256 != 0 || m.in_c % hkt != 0 || a->K != 9 * m.in_c) return false;
+    if (m.in_h < 1 || m.in_w < 1 || m.in_h * m.in_w > 256) return false;
+    int dy0 = m.dy[0], dx0 = m.dx[0];
+    for (int t = 1; t < 9; ++t) {
+        dy0 = m.dy[t] < dy0 ? m.dy[t] : dy0;
+        dx0 = m.dx[t] < dx0 ? m.dx[t] : dx0;
+    }
+    conv_taps_t tp;
+    tp.dy0 = dy0;
+    tp.dx0 = dx0;
+    for (int r = 0; r < 9; ++r) tp.wslot[r] = -1;
+    for (int t = 0; t < 9; ++t) {
+        const int dyi = m.dy[t] - dy0, dxi = m.dx[t] - dx0;
+        if (dyi > 2 || dxi > 2 || tp.wslot[3 * dxi + dyi] != -1 || m.wslot[t] < 0) return false;
+        tp.wslot[3 * dxi + dyi] = m.wslot[t];
+    }
+    if (out != nullptr) *out = tp;
+    return true;
+}
+
+int theia_gemm_conv_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t stream) {
+    conv_taps_t tp;
+    if (!theia_gemm_conv_pp_match(a, dtype, &tp)) {
+        theia_set_error("theia_gemm_nt: the row map is not a 3x3 stride-1 convolution with one 16x16 image per 256-row tile");
+        return THEIA_ERR_UNSUPPORTED;
+    }
+    constexpr int ring_bytes = 6 * 256 * 64 + 2 * 256 * 64 + 64;
+    constexpr int ep_bytes = 8 * 64 * (64 + 4) * 4;
+    constexpr int lds = ring_bytes > ep_bytes ? ring_bytes : ep_bytes;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_pp_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_pp_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int tiles = (a->M / 256) * cdiv_i(a->N, 256);
+    if (dtype == THEIA_BF16) hipLaunchKernelGGL(gemm_conv_pp_kernel<bf16_t>, dim3(tiles), dim3(512), lds, stream, *a, tp);
+    else hipLaunchKernelGGL(gemm_conv_pp_kernel<float>, dim3(tiles), dim3(512), lds, stream, *a, tp);
+    THEIA_CHECK_LAUNCH("theia_gemm_nt(conv)");
+    return THEIA_OK;
+}

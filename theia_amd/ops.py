@@ -126,30 +126,40 @@ GEMM_PROFILE: Optional[list] = None
 WGRAD_PROFILE: Optional[list] = None  # same for theia_gemm_wgrad launches
 
 
+KERNEL_NAMES = {128128: "128x128", 128064: "128x64", 256000: "256x256-2stage", 256256: "256x256", 256009: "256x256-conv"}
+
+
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int, K: int, rmap: RowMap, ldw: int, ldo: int,
             bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, act: int = N.ACT_NONE,
             aux_in: Optional[torch.Tensor] = None, aux_out: Optional[torch.Tensor] = None,
-            rowtab: Optional[torch.Tensor] = None, rowtab_period: int = 0, tile: int = 0) -> torch.Tensor:
+            rowtab: Optional[torch.Tensor] = None, rowtab_period: int = 0, tile: int = 0, plan_only: bool = False):
+    """tile: kernel request (0 = the library's choice; see theia_gemm_args_t.tile).  plan_only: launch nothing, return the code
+    of the kernel the library would run (theia_gemm_nt_plan)."""
     g = GemmArgs()
-    if tile == 0 and GEMM_TILE_HINT != 0:
-        if GEMM_TILE_HINT != 256256:
-            tile = GEMM_TILE_HINT if N.lib().theia_gemm_nt_tile(M, Nn, _dt(a)) != 128064 else 0
-        elif pp_supported(K, rmap.in_c, a.dtype) and N.lib().theia_gemm_nt_tile(M, Nn, _dt(a)) != 128064:
-            tile = 256256
-    g.tile = tile
     g.a, g.w, g.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
     g.bias, g.resid, g.aux_in, g.aux_out = N.ptr(bias), N.ptr(resid), N.ptr(aux_in), N.ptr(aux_out)
     g.rowtab, g.rowtab_period = N.ptr(rowtab), rowtab_period
     g.M, g.N, g.K, g.ldw, g.ldo, g.act = M, Nn, K, ldw, ldo, act
     g.map = rmap
+    if tile == 0 and GEMM_TILE_HINT != 0:
+        if GEMM_TILE_HINT == 128128:
+            tile = 128128 if N.lib().theia_gemm_nt_tile(M, Nn, _dt(a)) != 128064 else 0
+        elif N.lib().theia_gemm_nt_tile(M, Nn, _dt(a)) != 128064:  # 256256: every ping-pong kernel the problem admits
+            g.tile = 256009
+            if N.lib().theia_gemm_nt_plan(g, _dt(a)) == 256009:
+                tile = 256009
+            elif pp_supported(K, rmap.in_c, a.dtype):
+                tile = 256256
+    g.tile = tile
     assert a.dtype == w.dtype == out.dtype
+    if plan_only:
+        return N.lib().theia_gemm_nt_plan(g, _dt(a))
     if GEMM_PROFILE is not None:  # bench.py: HIP events on the launch stream around every theia_gemm_nt launch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         N.check(N.lib().theia_gemm_nt(g, _dt(a), N.stream_ptr()), "theia_gemm_nt")
         e1.record()
-        tl = tile or N.lib().theia_gemm_nt_tile(M, Nn, _dt(a))
-        GEMM_PROFILE.append((e0, e1, 2.0 * M * Nn * K, f"{tl // 1000}x{tl % 1000}", (M, Nn, K)))
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * Nn * K, KERNEL_NAMES.get(N.lib().theia_gemm_nt_plan(g, _dt(a)), "?"), (M, Nn, K)))
         return out
     N.check(N.lib().theia_gemm_nt(g, _dt(a), N.stream_ptr()), "theia_gemm_nt")
     return out

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Micro-benchmark of theia_gemm_nt / theia_gemm_wgrad on the hot-path shapes (tuning + rocprofv3 --pmc target).
 
-    python tools/gemm_bench.py [--what nt|wgrad|both] [--iters 20] [--shapes conv,fc1,...]
+    python tools/gemm_bench.py [--what nt|wgrad|both] [--iters 20] [--shapes conv16,fc1,...] [--tile 0|128128|256256|256009]
 """
 import argparse
 import os
@@ -14,6 +14,8 @@ from theia_amd import ops  # noqa: E402
 
 SHAPES = {  # name: (M, N, K, kind)
     "conv16": (32768, 768, 6912, "conv"),
+    "conv16d": (32768, 768, 6912, "conv_dgrad"),
+    "pad": (32768, 768, 6912, "pad"),
     "fc1": (25216, 3072, 768, "plain"),
     "fc2": (25216, 768, 3072, "plain"),
     "proj": (25216, 768, 768, "plain"),
@@ -27,22 +29,28 @@ def main():
     ap.add_argument("--what", default="both")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--shapes", default=",".join(SHAPES))
+    ap.add_argument("--tile", type=int, default=0, help="kernel request for theia_gemm_nt (0 = library's choice)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     T = torch.bfloat16
     for name in a.shapes.split(","):
         M, N, K, kind = SHAPES[name]
         C = 768
-        if kind == "conv":
+        if kind in ("conv", "conv_dgrad", "pad"):
             b = M // 256
-            plan = ops.plan_conv3x3(C, 16)
-            rmap, mpi = plan.fwd[0]
-            x = torch.randn(b, 256 * C, device=dev).to(T)
+            if kind == "pad":
+                plan = ops.plan_convT3x3(C, 14, 1, 0, 0, in_bs=197 * C, in_off=C)
+                x = torch.randn(b, 197 * C, device=dev).to(T)
+            else:
+                plan = ops.plan_conv3x3(C, 16)
+                x = torch.randn(b, 256 * C, device=dev).to(T)
+            rmap, mpi = plan.dgrad if kind == "conv_dgrad" else plan.fwd[0]
             w = (torch.randn(N, K, device=dev) * 0.02).to(T)
             out = torch.empty(M, N, dtype=T, device=dev)
 
             def run_nt():
-                ops.gemm_nt(x, w, out, M, N, K, rmap, K, N)
+                ops.gemm_nt(x, w, out, M, N, K, rmap, K, N, tile=a.tile)
+            kern = ops.KERNEL_NAMES.get(ops.gemm_nt(x, w, out, M, N, K, rmap, K, N, tile=a.tile, plan_only=True))
             dy = torch.randn(M, N, device=dev).to(T)
             splits = ops.wgrad_splits(M, N, K)
             slabs = torch.empty(splits * N * K, dtype=torch.float32, device=dev)
@@ -55,7 +63,8 @@ def main():
             out = torch.empty(M, N, dtype=T, device=dev)
 
             def run_nt():
-                ops.linear(x, w, out=out)
+                ops.linear(x, w, out=out, tile=a.tile)
+            kern = ops.KERNEL_NAMES.get(a.tile or ops.N.lib().theia_gemm_nt_tile(M, N, 1))
             dy = torch.randn(M, N, device=dev).to(T)
             g = torch.empty(N, K, dtype=torch.float32, device=dev)
             ws = torch.empty(ops.wgrad_splits(M, N, K) * N * K, dtype=torch.float32, device=dev)
@@ -63,7 +72,7 @@ def main():
             def run_wg():
                 ops.linear_wgrad(dy, x, g, False, ws)
         for label, fn in (("nt", run_nt), ("wgrad", run_wg)):
-            if a.what not in (label, "both"):
+            if a.what not in (label, "both") or (label == "wgrad" and kind in ("conv_dgrad", "pad")):
                 continue
             for _ in range(3):
                 fn()
@@ -75,7 +84,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / a.iters * 1e3
-            print(f"{label:5s} {name:7s} M={M} N={N} K={K}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF", flush=True)
+            print(f"{label:5s} {name:7s} M={M} N={N} K={K} [{kern if label == 'nt' else 'wgrad'}]: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF", flush=True)
 
 
 if __name__ == "__main__":
