@@ -9,7 +9,8 @@
 // (in_h*in_w pixel rows of 64 B) and the 9 taps read their MFMA fragments at SHIFTED pixel rows: lane (x = lane & 15) of
 // output row y reads pixel (y + dy, x + dx), or a row of zeros when that falls outside the image.  Per slice the stream is
 // 16 KB + 9 x 16 KB instead of 18 x 16 KB, and the fragments of one dx serve its three dy taps (30 + 36 ds_read_b128 per
-// slice and wave instead of 108).
+// slice and wave instead of 108).  Each image buffer carries 32 zero rows above and below the pixels (rows outside the image
+// in y); lanes whose pixel column is outside the image read the zero pad instead (address select, once per kernel).
 //
 // Unit u = (slice s, tap r = 3*dxi + dyi), 32 MFMAs per wave -- the role a half k-tile plays in gemm_pp.hip; the two wave
 // groups run one barrier apart and alternate R(u) (fragment reads + LDS-DMA issue) and M(u) (MFMAs).
@@ -39,8 +40,10 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int WM = 128, WN = 64, FM = 8, FN = 4;
     constexpr int SRP = 128;                     // rows staged per piece (512 threads x 16 B)
-    constexpr int BTILE = BN * 64, ATILE = BM * 64;
-    constexpr int A_OFF = NB * BTILE, Z_OFF = A_OFF + 2 * ATILE;
+    constexpr int BTILE = BN * 64;
+    constexpr int APAD = 32 * 64;                // 32 zero rows above and below the image: pixel rows y < 0 / y >= in_h read zeros
+    constexpr int ATILE = BM * 64 + 2 * APAD;    // one image-slice buffer: [pad | 256 pixel rows | pad]
+    constexpr int A_OFF = NB * BTILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -56,19 +59,29 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
     const T* __restrict__ W = reinterpret_cast<const T*>(p.w);
     const uint64_t zp = reinterpret_cast<uint64_t>(g_cv_zero_page);
 
-    // zero row of the image tile (read by fragments whose pixel is outside the image)
-    if (tid < 4) reinterpret_cast<uint4*>(smem + Z_OFF)[tid] = make_uint4(0, 0, 0, 0);
+    // zero pads of the two image buffers (4 x 2 KiB = 512 x 16 B): never touched by the LDS-DMA, read by fragments whose pixel
+    // row is above / below the image and by the lanes whose pixel column is outside it
+    {
+        const int pad = tid >> 7, o = (tid & 127) * 16;
+        *reinterpret_cast<uint4*>(smem + A_OFF + (pad >> 1) * ATILE + (pad & 1) * (APAD + BM * 64) + o) = make_uint4(0, 0, 0, 0);
+    }
 
     // ---- per-thread LDS-DMA sources: rows st_row and st_row + 128 of an image slice / of a weight tile ----
+    // Swizzle of the 16-byte chunks inside a 64-byte row (bank-conflict-free ds_read_b128): weight rows by their row index,
+    // image rows by the pixel's COLUMN x -- so that a fragment's address is (lane part) + (pixel row) * in_w * 64 for any in_w.
     const int st_chunk = tid & 3, st_row = tid >> 2;
     const int lchunk = st_chunk ^ cv_f(st_row);
     const int npix = mp.in_h * mp.in_w;
+    const float rcp_w = 1.0f / (float)mp.in_w;
     uint64_t a_src[2], w_src[2];
     uint32_t w_live[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int pix = st_row + SRP * i;
-        const uint64_t pa = reinterpret_cast<uint64_t>(A + (int64_t)img * mp.in_batch_stride + mp.in_offset + (int64_t)pix * mp.in_c + lchunk * EPC);
+        int px;
+        (void)gt_divmod(pix, mp.in_w, rcp_w, px);
+        const int achunk = st_chunk ^ cv_f(px);
+        const uint64_t pa = reinterpret_cast<uint64_t>(A + (int64_t)img * mp.in_batch_stride + mp.in_offset + (int64_t)pix * mp.in_c + achunk * EPC);
         a_src[i] = pix < npix ? pa : 0;  // 0: the zero page, not advanced with the slice
         const int n = n0 + st_row + SRP * i;
         w_live[i] = n < p.N ? 0xffffffffu : 0u;
@@ -86,7 +99,7 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
     };
     auto issue_a = [&](int s, int buf) {  // image slice s into image buffer buf
         const uint64_t off = (uint64_t)s * 64;
-        char* dst = smem + A_OFF + buf * ATILE + uwave * (16 * 64);
+        char* dst = smem + A_OFF + buf * ATILE + APAD + uwave * (16 * 64);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const uint64_t src = a_src[i] != 0 ? a_src[i] + off : zp;
@@ -111,7 +124,7 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
         issue_b(u, uc % 9, uc / 9);
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PD - 1)) : "memory");  // image slice 0 and weight tile 0 landed
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the zero row is written
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the zero pads are written
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (ugroup == 1) {  // group 1 runs one barrier behind group 0
@@ -120,38 +133,44 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
     }
 
     // ---- fragment addressing: lane (x = lane & 15, k-chunk fg) of output row y reads pixel (y + dy, x + dx) ----
+    // All LDS reads of the main loop are inline asm (gt_ds_read128: C++ loads would make the compiler drain the LDS-DMA queue
+    // at the top of every unit).  Weight fragments: one lane offset + immediates.  Image fragments of tap column dxi: address =
+    // a_lane[dxi] + (pixel row) * a_step[dxi]; lanes whose pixel column is outside the image point at the zero pad with step 0.
     const int frow = lane & 15, fg = lane >> 4;
-    const int y0 = wm * 8 + tp.dy0;          // first pixel row of this wave's fragment window (10 rows: 8 outputs + 2 halo)
-    const uint32_t zaddr = Z_OFF + fg * 16;
-    int bslot = 0;                           // ring slot of the current unit's weight tile
-    uint4 fb[FN], fa[FM];
+    const uint32_t smem_base = gt_lds_addr(smem);
+    const uint32_t lane_b = smem_base + (wn * WN + frow) * 64 + ((fg ^ cv_f(frow)) << 4);
+    const int y0 = wm * 8 + tp.dy0;  // first pixel row of this wave's 10-row window (8 output rows + 2 halo rows)
+    uint32_t a_lane[3], a_step[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int ix = frow + tp.dx0 + d;
+        const bool xok = (unsigned)ix < (unsigned)mp.in_w;
+        a_lane[d] = smem_base + A_OFF + (xok ? APAD + (y0 * mp.in_w + ix) * 64 + ((fg ^ cv_f(ix)) << 4) : fg * 16);
+        a_step[d] = xok ? mp.in_w * 64 : 0;
+    }
+    int bslot = 0;  // ring slot of the current unit's weight tile
+    gt_u32x4 fb[FN], fa[FM];
     for (int s = 0; s < nslice; ++s) {
-        const char* abuf = smem + A_OFF + (s & 1) * ATILE;
+        const uint32_t abuf = (s & 1) * ATILE;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             const int dxi = r / 3, dyi = r % 3;
             // ---------------- R(u): fragment reads + LDS-DMA issue
-            const char* sb = smem + bslot * BTILE;
-#pragma unroll
-            for (int i = 0; i < FN; ++i) {
-                const int row = wn * WN + i * 16 + frow;
-                fb[i] = *reinterpret_cast<const uint4*>(sb + row * 64 + ((fg ^ cv_f(row)) << 4));
+            {
+                const uint32_t ab = lane_b + bslot * BTILE;
+                gt_ds_read128<0>(fb[0], ab);
+                gt_ds_read128<1024>(fb[1], ab);
+                gt_ds_read128<2048>(fb[2], ab);
+                gt_ds_read128<3072>(fb[3], ab);
             }
             {
                 // The wave's 8 output rows of tap (dyi, dxi) read pixel rows y0 + dyi .. y0 + dyi + 7, shifted by dx.  Row q of
                 // the 10-row window lives in fa[q % 8]: dyi = 0 loads rows 0..7, dyi = 1 replaces row 0 by row 8, dyi = 2 row 1
                 // by row 9 (10 reads per dx, 8 fragment registers).
-                const int ix = frow + tp.dx0 + dxi;
-                const bool xok = (unsigned)ix < (unsigned)mp.in_w;
                 const int q_lo = dyi == 0 ? 0 : FM + dyi - 1, q_hi = dyi == 0 ? FM : FM + dyi;
+                const uint32_t aa = a_lane[dxi] + abuf;
 #pragma unroll
-                for (int q = q_lo; q < q_hi; ++q) {
-                    const int iy = y0 + q;
-                    const int row = iy * mp.in_w + ix;
-                    const bool ok = xok && (unsigned)iy < (unsigned)mp.in_h;
-                    const uint32_t off = ok ? (uint32_t)(abuf - smem) + row * 64 + ((fg ^ cv_f(row)) << 4) : zaddr;
-                    fa[q % FM] = *reinterpret_cast<const uint4*>(smem + off);
-                }
+                for (int q = q_lo; q < q_hi; ++q) gt_ds_read128<0>(fa[q % FM], aa + q * a_step[dxi]);
             }
             {
                 // prefetch: weight tile of unit u + PD (clamped at the tail), image slice s + 1 once per slice
@@ -164,7 +183,7 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
                 // read), so the number of LDS-DMA operations younger than a given weight tile is a compile-time constant
                 if (r == 2) issue_a(min(s + 1, nslice - 1), (s + 1) & 1);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            gt_wait_lds(fb, fa);
             // weight tile u + 1 landed: younger than it are tiles u + 2 .. u + 5 (8 operations) and, in the five units after an
             // image slice was queued (behind tile u_A + 5), that slice's two pieces
             if (r >= 2 && r <= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PD - 1) + 2) : "memory");
@@ -177,7 +196,7 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
 #pragma unroll
             for (int j = 0; j < FM; ++j)
 #pragma unroll
-                for (int i = 0; i < FN; ++i) GtMma<T>::run(acc[i][j], fb[i], fa[(j + dyi) % FM]);
+                for (int i = 0; i < FN; ++i) gt_mma<T>(acc[i][j], fb[i], fa[(j + dyi) % FM]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -229,7 +248,7 @@ int theia_gemm_conv_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t
         theia_set_error("theia_gemm_nt: the row map is not a 3x3 stride-1 convolution with one 16x16 image per 256-row tile");
         return THEIA_ERR_UNSUPPORTED;
     }
-    constexpr int ring_bytes = 6 * 256 * 64 + 2 * 256 * 64 + 64;
+    constexpr int ring_bytes = 6 * 256 * 64 + 2 * (256 * 64 + 2 * 32 * 64);
     constexpr int ep_bytes = 8 * 64 * (64 + 4) * 4;
     constexpr int lds = ring_bytes > ep_bytes ? ring_bytes : ep_bytes;
     static bool attr_set = false;

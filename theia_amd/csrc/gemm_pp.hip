@@ -172,12 +172,16 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
 
     PP_PHASE(3)
     const int frow = lane & 15, fg = lane >> 4;
-    uint4 fb[FN];
+    // Fragment addresses: rows 16 apart share the swizzle (pp_f looks at bits 2..3 of the row), so the 8 A fragments / 4 B
+    // fragments of a wave are 1 KiB apart: one lane-dependent offset each + immediates.  The reads are inline asm (see
+    // gt_ds_read128: a C++ load here would make the compiler drain every in-flight LDS-DMA at the top of each iteration).
+    const uint32_t smem_base = gt_lds_addr(smem);
+    const uint32_t lane_a = smem_base + (wm * WM + frow) * 64 + ((fg ^ pp_f(frow)) << 4);
+    const uint32_t lane_b = smem_base + BM * 64 + (wn * WN + frow) * 64 + ((fg ^ pp_f(frow)) << 4);
+    gt_u32x4 fb[FN], fa[FM];
 #ifdef PP_EXP_NOLDS
-    const int h_nolds = p.K < 0 ? 1 : -1;  // never true, but unknown to the compiler
-    uint4 fa[FM];
-    for (int j = 0; j < FM; ++j) fa[j] = make_uint4(tid, tid, tid, tid);
-    for (int i = 0; i < FN; ++i) fb[i] = make_uint4(tid, tid, tid, tid);
+    for (int j = 0; j < FM; ++j) fa[j] = (gt_u32x4){(unsigned)tid, (unsigned)tid, (unsigned)tid, (unsigned)tid};
+    for (int i = 0; i < FN; ++i) fb[i] = (gt_u32x4){(unsigned)tid, (unsigned)tid, (unsigned)tid, (unsigned)tid};
 #endif
     for (int h = 0; h < nh; ++h) {
         const int hp = min(h + NSTAGE - 1, nh - 1);  // half-tile prefetched during this iteration (clamped at the tail)
@@ -189,30 +193,25 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         const uint64_t coff = (uint64_t)(hp - cur_tap * hpt) * 64;
         char* na = smem + ((h + NSTAGE - 1) & (NSTAGE - 1)) * STAGE + uwave * (16 * 64);
         char* nb = na + BM * 64;
-        const char* sa = smem + (h & (NSTAGE - 1)) * STAGE;
-        const char* sb = sa + BM * 64;
+        const uint32_t soff = (uint32_t)(h & (NSTAGE - 1)) * STAGE;
         {
             // ---------------- R(h): 12 fragment reads + the 4 LDS-DMA pieces of half-tile h+3
             PP_STAMP(0)
 #ifndef PP_EXP_NOLDS
-            uint4 fa[FM];
+            const uint32_t ab = lane_b + soff, aa = lane_a + soff;
+            gt_ds_read128<0>(fb[0], ab);
+            gt_ds_read128<1024>(fb[1], ab);
+            gt_ds_read128<2048>(fb[2], ab);
+            gt_ds_read128<3072>(fb[3], ab);
+            gt_ds_read128<0>(fa[0], aa);
+            gt_ds_read128<1024>(fa[1], aa);
+            gt_ds_read128<2048>(fa[2], aa);
+            gt_ds_read128<3072>(fa[3], aa);
+            gt_ds_read128<4096>(fa[4], aa);
+            gt_ds_read128<5120>(fa[5], aa);
+            gt_ds_read128<6144>(fa[6], aa);
+            gt_ds_read128<7168>(fa[7], aa);
 #endif
-#pragma unroll
-            for (int i = 0; i < FN; ++i) {
-                const int row = wn * WN + i * 16 + frow;
-#ifdef PP_EXP_NOLDS
-                if (h == h_nolds)
-#endif
-                fb[i] = *reinterpret_cast<const uint4*>(sb + row * 64 + ((fg ^ pp_f(row)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < FM; ++j) {
-                const int row = wm * WM + j * 16 + frow;
-#ifdef PP_EXP_NOLDS
-                if (h == h_nolds)
-#endif
-                fa[j] = *reinterpret_cast<const uint4*>(sa + row * 64 + ((fg ^ pp_f(row)) << 4));
-            }
             PP_STAMP2(0)
 #ifndef PP_GLDS_IN_M  // default: the LDS-DMA pieces are issued in the R segment (their ~60-100 issue cycles each overlap the
                       // OTHER group's MFMAs); -DPP_GLDS_IN_M puts them between this group's MFMAs (5% slower, 2 A/B runs)
@@ -221,11 +220,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
             for (int q = 0; q < LPH; ++q) issue_piece(q, coff, na, nb);
 #endif
             PP_STAMP2(1)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            gt_wait_lds(fb, fa);
             PP_STAMP(1)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPH) : "memory");  // half-tile h+1 landed; h+2, h+3 may be in flight
 #else
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            gt_wait_lds(fb, fa);
             PP_STAMP(1)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPH) : "memory");  // half-tile h+1 landed; h+2 may still be in flight
 #endif
@@ -240,9 +239,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
             for (int j = 0; j < FM; ++j) {
 #pragma unroll
 #ifdef PP_EXP_NOMFMA
-                for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(fb[i].x), "v"(fb[i].y), "v"(fb[i].z), "v"(fb[i].w), "v"(fa[j].x), "v"(fa[j].y), "v"(fa[j].z), "v"(fa[j].w));
+                for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(fb[i]), "v"(fa[j]));
 #else
-                for (int i = 0; i < FN; ++i) GtMma<T>::run(acc[i][j], fb[i], fa[j]);
+                for (int i = 0; i < FN; ++i) gt_mma<T>(acc[i][j], fb[i], fa[j]);
 #endif
 #ifdef PP_GLDS_IN_M
                 if ((j & 1) == 0) issue_piece(j >> 1, coff, na, nb);

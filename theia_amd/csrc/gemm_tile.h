@@ -24,6 +24,32 @@ template <> struct GtMma<float> {
     }
 };
 
+// the same on fragments held as 4 x u32 vectors (what the inline-asm LDS reads below produce)
+template <typename T> __device__ __forceinline__ void gt_mma(gt_f32x4& acc, const gt_u32x4& a, const gt_u32x4& b) {
+    if constexpr (sizeof(T) == 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gt_bf16x8, a), __builtin_bit_cast(gt_bf16x8, b), acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[k]), __uint_as_float(b[k]), acc, 0, 0, 0);
+    }
+}
+
+// ds_read_b128 as inline asm.  A plain C++ LDS load in a loop that also issues LDS-DMA (global_load_lds) makes hipcc put
+// `s_waitcnt vmcnt(0)` in front of the first load of every iteration (it cannot tell the ring slot being read from the slot being
+// filled), which drains the whole prefetch pipeline once per k-step: measured as a kernel bound by the LATENCY of one operand
+// tile.  The asm form is invisible to that bookkeeping; the kernels order it themselves with counted vmcnt waits + barriers, and
+// tie the destination registers to their own `s_waitcnt lgkmcnt(0)` (gt_wait_lds) before the MFMAs read them.
+template <int OFF> __device__ __forceinline__ void gt_ds_read128(gt_u32x4& dst, uint32_t lds_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF));
+}
+__device__ __forceinline__ void gt_wait_lds(gt_u32x4 (&b)[4], gt_u32x4 (&a)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]),
+                   "+v"(a[6]), "+v"(a[7])::"memory");
+}
+// LDS byte address of a pointer into the workgroup's dynamic shared memory
+__device__ __forceinline__ uint32_t gt_lds_addr(const void* p) { return (uint32_t)reinterpret_cast<uintptr_t>(p); }
+
 // hardware places block b on XCD b % 8; give each XCD a contiguous range of tiles (bijective for any grid size)
 __device__ __forceinline__ int gt_xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7;
