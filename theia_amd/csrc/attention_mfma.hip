@@ -52,7 +52,10 @@ __device__ __forceinline__ uint4 am_tr(const char* __restrict__ base, int s, int
     return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 
-__device__ __forceinline__ uint32_t am_pack2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+__device__ __forceinline__ uint32_t am_pack2(float a, float b) { return pack2_bf16(a, b); }
+constexpr float AM_C = 0.125f * 1.4426950408889634f;  // softmax scale 1/sqrt(64) folded with log2(e): exp(x/8 - m) = exp2(x*AM_C - m*log2e)
+constexpr float AM_LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float am_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32 (inputs here are <= 0 or -inf)
 __device__ __forceinline__ uint4 am_pack(const am_f32x4& t0, const am_f32x4& t1) {
     return make_uint4(am_pack2(t0[0], t0[1]), am_pack2(t0[2], t0[3]), am_pack2(t1[0], t1[1]), am_pack2(t1[2], t1[3]));
 }
@@ -71,6 +74,9 @@ __device__ __forceinline__ void am_store4(bf16_t* p, const am_f32x4& v, float sc
 }
 
 // ================================================================================================ forward
+// TAIL: n > 192, i.e. only the last 16-key tile straddles n and needs its keys masked (the per-element compare + select of the
+// generic form was a quarter of the kernel's VALU instructions; DeiT: n = 197 / 196 / 204)
+template <bool TAIL>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                             float* __restrict__ lse, int n, int h) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -100,21 +106,22 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
             am_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             am_mma(acc, am_nat(sK, kt * 16, 0, lane), qf[0]);
             am_mma(acc, am_nat(sK, kt * 16, 1, lane), qf[1]);
+            if (!TAIL || kt == AM_TILES - 1) {  // keys beyond n: probability 0
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + g * 4 + r;
-                acc[r] = key < n ? acc[r] * 0.125f : -INFINITY;
-                mx = fmaxf(mx, acc[r]);
+                for (int r = 0; r < 4; ++r) acc[r] = kt * 16 + g * 4 + r < n ? acc[r] : -INFINITY;
             }
-            s[kt] = acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[r]);
+            s[kt] = acc;  // raw q.k (the 1/8 scale is folded into the exponent below)
         }
         mx = am_rmax(mx);
+        const float mc = mx * AM_C;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < AM_TILES; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(s[kt][r] - mx);
+                const float p = am_exp2(fmaf(s[kt][r], AM_C, -mc));
                 s[kt][r] = p;
                 sum += p;
             }
@@ -134,12 +141,13 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
             bf16_t* orow = o + ((int64_t)bi * n + qrow) * D + hi * 64 + g * 4;
 #pragma unroll
             for (int df = 0; df < 4; ++df) am_store4(orow + df * 16, oa[df], inv);
-            if (g == 0) lse[(int64_t)bh * n + qrow] = mx + __logf(sum);
+            if (g == 0) lse[(int64_t)bh * n + qrow] = mx * 0.125f + __logf(sum);
         }
     }
 }
 
 // ================================================================================================ backward: dQ (+ delta)
+template <bool TAIL>
 __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                bf16_t* __restrict__ dqkv, float* __restrict__ delta, int n, int h) {
@@ -175,30 +183,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16_t* __r
             }
         }
         dl = am_rsum(dl);
-        const float lq = qok ? lse[(int64_t)bh * n + qrow] : 0.f;
-        am_f32x4 ds[AM_TILES + 1];
-#pragma unroll
-        for (int kt = 0; kt < AM_TILES; ++kt) {
-            am_f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            am_mma(st, am_nat(sK, kt * 16, 0, lane), qf[0]);
-            am_mma(st, am_nat(sK, kt * 16, 1, lane), qf[1]);
-            am_mma(dp, am_nat(sV, kt * 16, 0, lane), gf[0]);
-            am_mma(dp, am_nat(sV, kt * 16, 1, lane), gf[1]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + g * 4 + r;
-                const float p = key < n ? __expf(st[r] * 0.125f - lq) : 0.f;
-                st[r] = p * (dp[r] - dl) * 0.125f;
-            }
-            ds[kt] = st;
-        }
-        ds[AM_TILES] = (am_f32x4){0.f, 0.f, 0.f, 0.f};
+        const float lq2 = qok ? lse[(int64_t)bh * n + qrow] * AM_LOG2E : 0.f;
+        // dS needs no row maximum (the forward's log-sum-exp is saved), so the 13 key tiles are streamed two at a time straight
+        // into the dQ accumulators: nothing but one packed dS fragment lives across a step (the version that first computed all
+        // 13 dS tiles needed 334 registers -> one wave per SIMD)
         am_f32x4 dq[4];
 #pragma unroll
         for (int df = 0; df < 4; ++df) dq[df] = (am_f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1
         for (int ks = 0; ks < AM_KSTEPS; ++ks) {
-            const uint4 sb = am_pack(ds[2 * ks], ds[2 * ks + 1]);
+            am_f32x4 dsv[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kt = 2 * ks + t;
+                am_f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                if (kt < AM_TILES) {  // wave-uniform (the 14th tile of the last step does not exist)
+                    am_mma(st, am_nat(sK, kt * 16, 0, lane), qf[0]);
+                    am_mma(st, am_nat(sK, kt * 16, 1, lane), qf[1]);
+                    am_mma(dp, am_nat(sV, kt * 16, 0, lane), gf[0]);
+                    am_mma(dp, am_nat(sV, kt * 16, 1, lane), gf[1]);
+                }
+                if (!TAIL || kt >= AM_TILES - 1) {  // keys beyond n get probability 0
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[r] = kt * 16 + g * 4 + r < n ? st[r] : -INFINITY;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dsv[t][r] = am_exp2(fmaf(st[r], AM_C, -lq2)) * (dp[r] - dl) * 0.125f;
+            }
+            const uint4 sb = am_pack(dsv[0], dsv[1]);
 #pragma unroll
             for (int df = 0; df < 4; ++df) am_mma(dq[df], am_tr(sK, ks, df, lane), sb);
         }
@@ -227,7 +239,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16_t* __
     am_stage(base, rs, n, AM_ROWS, sQ);
     am_stage(d_o + (int64_t)bi * n * D + hi * 64, (int64_t)D, n, AM_ROWS, sG);
     for (int i = threadIdx.x; i < AM_ROWS; i += blockDim.x) {
-        sL[i] = i < n ? lse[(int64_t)bh * n + i] : INFINITY;
+        sL[i] = i < n ? lse[(int64_t)bh * n + i] * AM_LOG2E : INFINITY;  // log2-domain; +inf beyond n: probability 0
         sD[i] = i < n ? delta[(int64_t)bh * n + i] : 0.f;
     }
     __syncthreads();
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16_t* __
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qi = q0 + g * 4 + r;
-                    const float pv = __expf(sa[r] * 0.125f - sL[qi]);
+                    const float pv = am_exp2(fmaf(sa[r], AM_C, -sL[qi]));
                     p[t][r] = pv;
                     dsv[t][r] = pv * (da[r] - sD[qi]) * 0.125f;
                 }
@@ -297,8 +309,10 @@ static void am_set_lds(const void* kern, int bytes) {
 
 int theia_attention_fwd_mfma(const void* qkv, void* o, float* lse, int b, int n, int h, hipStream_t s) {
     const int lds = (208 + AM_ROWS) * AM_PITCH;
-    am_set_lds(reinterpret_cast<const void*>(attn_fwd_mfma_kernel), lds);
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(b * h), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, n, h);
+    am_set_lds(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<true>), lds);
+    am_set_lds(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<false>), lds);
+    if (n > 192) hipLaunchKernelGGL(attn_fwd_mfma_kernel<true>, dim3(b * h), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, n, h);
+    else hipLaunchKernelGGL(attn_fwd_mfma_kernel<false>, dim3(b * h), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, n, h);
     THEIA_CHECK_LAUNCH("theia_attention_fwd(mfma)");
     return THEIA_OK;
 }
@@ -307,10 +321,15 @@ int theia_attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, co
                              int b, int n, int h, hipStream_t s) {
     const int lds1 = (AM_ROWS + 208) * AM_PITCH;
     const int lds2 = 2 * AM_ROWS * AM_PITCH + 2 * AM_ROWS * (int)sizeof(float);
-    am_set_lds(reinterpret_cast<const void*>(attn_bwd_dq_mfma_kernel), lds1);
+    am_set_lds(reinterpret_cast<const void*>(attn_bwd_dq_mfma_kernel<true>), lds1);
+    am_set_lds(reinterpret_cast<const void*>(attn_bwd_dq_mfma_kernel<false>), lds1);
     am_set_lds(reinterpret_cast<const void*>(attn_bwd_dkv_mfma_kernel), lds2);
-    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(b * h), dim3(256), lds1, s, (const bf16_t*)qkv, (const bf16_t*)o,
-                       (const bf16_t*)d_o, lse, (bf16_t*)dqkv, delta, n, h);
+    if (n > 192)
+        hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, dim3(b * h), dim3(256), lds1, s, (const bf16_t*)qkv, (const bf16_t*)o,
+                           (const bf16_t*)d_o, lse, (bf16_t*)dqkv, delta, n, h);
+    else
+        hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<false>, dim3(b * h), dim3(256), lds1, s, (const bf16_t*)qkv, (const bf16_t*)o,
+                           (const bf16_t*)d_o, lse, (bf16_t*)dqkv, delta, n, h);
     THEIA_CHECK_LAUNCH("theia_attention_bwd(dq mfma)");
     hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(b * h), dim3(256), lds2, s, (const bf16_t*)qkv, (const bf16_t*)d_o, lse,
                        delta, (bf16_t*)dqkv, n, h);

@@ -37,11 +37,13 @@ typedef uint16_t bf16_t;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                          // round-nearest-even
-    return (bf16_t)(u >> 16);
+// f32 -> bf16, round-to-nearest-even: gfx950's v_cvt_pk_bf16_f32 (one instruction per PAIR; the bit-twiddling form it replaces
+// was ~6 VALU instructions per element and made the attention kernels and every bf16 epilogue VALU-bound)
+typedef __attribute__((ext_vector_type(2))) __bf16 theia_bf16x2_v;
+typedef __attribute__((ext_vector_type(2))) float theia_f32x2_v;
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((theia_f32x2_v){lo, hi}, theia_bf16x2_v));
 }
 
 template <typename T> struct Elem;
@@ -76,10 +78,7 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
-    uint32_t w[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
-    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
 }
 
 // ----------------------------------------------------------------------------------

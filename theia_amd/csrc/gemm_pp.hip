@@ -51,7 +51,9 @@ __device__ unsigned long long g_pp_phase[2][8][7];
 
 __device__ __forceinline__ int pp_f(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
-template <typename T>
+// CXXR: A/B switch (THEIA_PP_READS=cxx) -- fragment reads as plain C++ LDS loads, the form in which hipcc puts `s_waitcnt vmcnt(0)`
+// in front of them (every LDS-DMA in flight is drained at the top of each iteration)
+template <typename T, bool CXXR = false>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t p) {
     constexpr int BM = 256, BN = 256, WAVES_N = 4;
     constexpr int NSTAGE = 4;
@@ -199,6 +201,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
             PP_STAMP(0)
 #ifndef PP_EXP_NOLDS
             const uint32_t ab = lane_b + soff, aa = lane_a + soff;
+            if constexpr (CXXR) {
+#pragma unroll
+                for (int i = 0; i < FN; ++i) fb[i] = *reinterpret_cast<const gt_u32x4*>(smem + (ab - smem_base) + i * 1024);
+#pragma unroll
+                for (int j = 0; j < FM; ++j) fa[j] = *reinterpret_cast<const gt_u32x4*>(smem + (aa - smem_base) + j * 1024);
+            } else {
             gt_ds_read128<0>(fb[0], ab);
             gt_ds_read128<1024>(fb[1], ab);
             gt_ds_read128<2048>(fb[2], ab);
@@ -211,6 +219,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
             gt_ds_read128<5120>(fa[5], aa);
             gt_ds_read128<6144>(fa[6], aa);
             gt_ds_read128<7168>(fa[7], aa);
+            }
 #endif
             PP_STAMP2(0)
 #ifndef PP_GLDS_IN_M  // default: the LDS-DMA pieces are issued in the R segment (their ~60-100 issue cycles each overlap the
@@ -283,7 +292,14 @@ int theia_gemm_nt_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t s
         attr_set = true;
     }
     const int tiles = cdiv_i(a->M, 256) * cdiv_i(a->N, 256);
-    if (dtype == THEIA_BF16) hipLaunchKernelGGL(gemm_nt_pp_kernel<bf16_t>, dim3(tiles), dim3(512), lds, stream, *a);
+    static int cxx_reads = -1;
+    if (cxx_reads < 0) {
+        const char* e = getenv("THEIA_PP_READS");
+        cxx_reads = (e != nullptr && strcmp(e, "cxx") == 0) ? 1 : 0;
+        if (cxx_reads) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
+    if (dtype == THEIA_BF16 && cxx_reads) hipLaunchKernelGGL((gemm_nt_pp_kernel<bf16_t, true>), dim3(tiles), dim3(512), lds, stream, *a);
+    else if (dtype == THEIA_BF16) hipLaunchKernelGGL(gemm_nt_pp_kernel<bf16_t>, dim3(tiles), dim3(512), lds, stream, *a);
     else hipLaunchKernelGGL(gemm_nt_pp_kernel<float>, dim3(tiles), dim3(512), lds, stream, *a);
     THEIA_CHECK_LAUNCH("theia_gemm_nt(pp)");
     return THEIA_OK;

@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(const theia_cast_job_t*
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(jb.dst) + o) = v;
                 } else {
                     uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                    pk.x = pack2_bf16(v.x, v.y);
+                    pk.y = pack2_bf16(v.z, v.w);
                     *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(jb.dst) + o) = pk;
                 }
             }
