@@ -209,8 +209,16 @@ int theia_resize_u8(const uint8_t* src, uint8_t* dst, uint8_t* tmp, int b, int i
  * ---------------------------------------------------------------------------------------------- */
 int theia_patchify_u8(const uint8_t* img, const float* lut, void* out, int b, int channels_last, int dtype,
                       void* stream);
+/* the same for H x W images (interpolate_pos_encoding on non-224 inputs, backbones.py:314-341): [b, H, W, 3] / [b, 3, H, W] ->
+ * [b * (H/16) * (W/16), 768]; pixels beyond the last whole 16x16 patch are not read (Conv2d stride 16) */
+int theia_patchify_u8_hw(const uint8_t* img, const float* lut, void* out, int b, int H, int W, int channels_last, int dtype,
+                         void* stream);
 /* h[b, 0, :] = cls + pos[0]  (token 0 of every image; modeling_vit.py:148-149,159) */
 int theia_write_cls(const float* cls, const float* pos, void* h, int b, int ntok, int D, int dtype, void* stream);
+/* h[b, t0 + r, :] = tok[r, :] + pos[r, :], r < cnt  (tok, pos: f32 [cnt, D]): CLS token, and the register tokens appended
+ * after the patches by the reg- students (backbones.py:196-205) */
+int theia_write_tokens(const float* tok, const float* pos, void* h, int b, int ntok, int t0, int cnt, int D, int dtype,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K2: row LayerNorm over the last dim (eps 1e-12 in the ViT; modeling_vit.py:261-262,348)

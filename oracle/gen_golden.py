@@ -13,7 +13,8 @@ The fixtures hold data only -- no reference source text.  Usage (in the build co
 
 Cases (SURVEY.md §8c): G1 tiny+dinov2 B=8; G2 tiny+cdiv B=2; G3 tiny+cddsv B=2; G4 small+cddsv B=1;
 G5 base+cddsv B=1; G6 handle_feature_output modes; G7 input-layout equivalence; G8 bf16 feature
-norm; G9 DP 2 ranks x b=2 vs 1 x b=4 (gloo DDP on the reference); G10 per-op micro goldens.
+norm; G9 DP 2 ranks x b=2 vs 1 x b=4 (gloo DDP on the reference); G10 per-op micro goldens; G15 / G16 nocls- and reg-
+students; G17 position-embedding interpolation on non-224 inputs (all three students).
 """
 from __future__ import annotations
 
@@ -62,9 +63,32 @@ def import_reference():
         return ViTImageProcessorPil(image_mean=list(O.IMAGENET_MEAN), image_std=list(O.IMAGENET_STD),
                                     size={"height": 224, "width": 224}, do_resize=True)
 
+    def fake_config_from_pretrained(name, *a, **k):
+        D, nh, F = O.ARCH[name]
+        return ViTConfig(hidden_size=D, num_attention_heads=nh, intermediate_size=F)
+
     transformers.AutoModel.from_pretrained = staticmethod(fake_model_from_pretrained)
     transformers.AutoModel.from_config = staticmethod(fake_model_from_config)
     transformers.AutoProcessor.from_pretrained = staticmethod(fake_processor_from_pretrained)
+    transformers.AutoConfig.from_pretrained = staticmethod(fake_config_from_pretrained)
+    # The reference's nocls- / reg- embeddings (backbones.py:26-209) were written against transformers 4.4x: they read
+    # `self.config` of ViTEmbeddings and pass `interpolate_pos_encoding=` to ViTPatchEmbeddings.forward.  transformers 5.x has
+    # neither (the flag only switched off the input-size check there).  Two compatibility shims, nothing else, let the
+    # reference's own classes run unchanged:
+    from transformers.models.vit import modeling_vit as MV
+    if not getattr(MV.ViTEmbeddings, "_theia_compat", False):
+        _init, _pf = MV.ViTEmbeddings.__init__, MV.ViTPatchEmbeddings.forward
+
+        def emb_init(self, config, use_mask_token=False):
+            _init(self, config, use_mask_token)
+            self.config = config
+
+        def patch_forward(self, pixel_values, interpolate_pos_encoding=False):
+            return _pf(self, pixel_values)
+
+        MV.ViTEmbeddings.__init__ = emb_init
+        MV.ViTPatchEmbeddings.forward = patch_forward
+        MV.ViTEmbeddings._theia_compat = True
     from theia.models.rvfm import RobotVisionFM
     from theia.foundation_models.common import get_model_feature_size
     from theia.models.utils import handle_feature_output
@@ -283,6 +307,40 @@ def gen_g14(RobotVisionFM, gmfs):
     np.savez_compressed(os.path.join(OUT, "g14_deit_processor.npz"), **fx)
 
 
+def gen_g17(RobotVisionFM, gmfs):
+    """interpolate_pos_encoding on non-224 input with do_resize=False (backbones.py:314-341 -> HF modeling_vit.py:89-127 for
+    DeiT; the reference's own interpolate_pos_encoding for nocls- / reg-, backbones.py:39-69,146-177): forward_feature of the
+    reference on 160x192 images, and the gradient that flows back through the interpolation into position_embeddings."""
+    print("[gen_golden] G17", flush=True)
+    teachers = O.TEACHER_SETS["dinov2"]
+    fx = {}
+    hh, ww, b = 160, 192, 2
+    img = torch.from_numpy((O._hash_uniform(b * hh * ww * 3, 700) * 0.5 + 0.5).reshape(b, hh, ww, 3) * 255.999).to(torch.uint8)
+    fx["img"] = img.numpy()
+    for tag, bb in (("deit", "facebook/deit-tiny-patch16-224"), ("nocls", "nocls-facebook/deit-tiny-patch16-224"),
+                    ("reg", "reg-facebook/deit-tiny-patch16-224")):
+        model, params = build_reference(RobotVisionFM, gmfs, bb, teachers)
+        model.train()
+        z = model.forward_feature(img, do_resize=False, interpolate_pos_encoding=True)
+        zz = z.detach().numpy().reshape(-1)
+        zi = sample_idx(zz.size, 64, 23)
+        fx[f"{tag}_z_shape"] = np.array(z.shape)
+        fx[f"{tag}_z_idx"] = zi
+        fx[f"{tag}_z_val"] = zz[zi]
+        fx[f"{tag}_z_abssum"] = np.array(np.abs(zz.astype(np.float64)).sum())
+        w = torch.from_numpy(O._hash_uniform(z.numel(), 77).reshape(tuple(z.shape)).copy())
+        (z * w).sum().backward()
+        sdp = dict(model.named_parameters())
+        for short, k in (("pos", "backbone.model.embeddings.position_embeddings"), ("fc1", "backbone.model.layers.3.mlp.fc1.weight"),
+                         ("patch", "backbone.model.embeddings.patch_embeddings.projection.weight")):
+            g = sdp[k].grad.detach().numpy().reshape(-1)
+            gi = sample_idx(g.size, 16, 29)
+            fx[f"{tag}_g{short}_norm"] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            fx[f"{tag}_g{short}_idx"] = gi
+            fx[f"{tag}_g{short}_val"] = g[gi]
+    np.savez_compressed(os.path.join(OUT, "g17_interpolate_pos.npz"), **fx)
+
+
 def gen_g8():
     print("[gen_golden] G8", flush=True)
     sys.path.insert(0, REF_SRC)
@@ -437,6 +495,12 @@ def main():
     if want("g13"):  # CLS-token distillation heads (train_rvfm.py distill_cls): a spatial head + two "_cls" heads
         run_case("g13_tiny_dinov2_cls_b2", "facebook/deit-tiny-patch16-224",
                  ["facebook/dinov2-large", "facebook/dinov2-large_cls", "openai/clip-vit-large-patch14_cls"], 2, RobotVisionFM, gmfs)
+    if want("g15"):  # student without CLS token (backbones.py:344-416)
+        run_case("g15_nocls_tiny_dinov2_b2", "nocls-facebook/deit-tiny-patch16-224", T["dinov2"], 2, RobotVisionFM, gmfs)
+    if want("g16"):  # student with 7 register tokens (backbones.py:419-503)
+        run_case("g16_reg_tiny_dinov2_b2", "reg-facebook/deit-tiny-patch16-224", T["dinov2"], 2, RobotVisionFM, gmfs)
+    if want("g17"):
+        gen_g17(RobotVisionFM, gmfs)
     if want("g6"):
         gen_g6_g7(RobotVisionFM, gmfs, hfo)
     if want("g8"):

@@ -75,6 +75,24 @@ ARCH: Dict[str, Tuple[int, int, int]] = {
     "facebook/deit-small-patch16-224": (384, 6, 1536),
     "facebook/deit-base-patch16-224": (768, 12, 3072),
 }
+NUM_REG_TOKENS = 7  # DeiTReg default (backbones.py:419)
+
+
+def backbone_variant(backbone: str) -> "Tuple[str, bool, int]":
+    """(base model name, has CLS token, number of register tokens) of a backbone name: "nocls-<name>" is the student without
+    CLS token (backbones.py:344-372), "reg-<name>" the one with 7 register tokens appended (backbones.py:419-451);
+    dispatch order as build_backbone (:519-526): "reg" is tested first."""
+    if backbone.startswith("reg-"):
+        return backbone[4:], True, NUM_REG_TOKENS
+    if backbone.startswith("nocls-"):
+        return backbone[6:], False, 0
+    return backbone, True, 0
+
+
+def _arch(backbone: str) -> "Tuple[int, int, int]":
+    return ARCH[backbone_variant(backbone)[0]]
+
+
 NUM_LAYERS = 12
 PATCH = 16
 IMAGE = 224
@@ -110,11 +128,16 @@ def param_shapes(backbone: str, teachers: Sequence[str]) -> "Dict[str, Tuple[int
 
     Names are those observed for the reference under transformers 5.x.
     """
-    D, _h, F = ARCH[backbone]
+    D, _h, F = _arch(backbone)
+    _base, has_cls, nreg = backbone_variant(backbone)
     shapes: Dict[str, Tuple[int, ...]] = {}
     e = "backbone.model.embeddings."
-    shapes[e + "cls_token"] = (1, 1, D)
+    if has_cls:  # ViTEmbeddingsNoCLS sets cls_token = None (backbones.py:36): the parameter disappears from the state_dict
+        shapes[e + "cls_token"] = (1, 1, D)
     shapes[e + "position_embeddings"] = (1, NTOK, D)
+    if nreg:  # ViTEmbeddingsReg (backbones.py:134-137), registered after position_embeddings
+        shapes[e + "reg_token"] = (1, nreg, D)
+        shapes[e + "reg_pos_embed"] = (1, nreg, D)
     shapes[e + "patch_embeddings.projection.weight"] = (D, 3, PATCH, PATCH)
     shapes[e + "patch_embeddings.projection.bias"] = (D,)
     for i in range(NUM_LAYERS):
@@ -181,7 +204,7 @@ def synth_params(backbone: str, teachers: Sequence[str], seed: int = 0) -> "Dict
             v = 0.05 * u
         elif leaf == "bias":
             v = 0.02 * u
-        elif leaf in ("cls_token", "position_embeddings"):
+        elif leaf in ("cls_token", "position_embeddings", "reg_token", "reg_pos_embed"):
             v = 0.5 * u
         else:
             if len(shape) == 4 and "patch_embeddings" in name:
@@ -278,10 +301,10 @@ def to_bhwc_uint8(x) -> torch.Tensor:
     return x.contiguous()
 
 
-def preprocess(images, do_rescale: bool = True, do_normalize: bool = True) -> torch.Tensor:
-    """uint8 images -> fp32 [b,224,224,3] (NHWC)."""
+def preprocess(images, do_rescale: bool = True, do_normalize: bool = True, any_size: bool = False) -> torch.Tensor:
+    """uint8 images -> fp32 [b,H,W,3] (NHWC); H = W = 224 unless any_size (do_resize=False + interpolate_pos_encoding)."""
     x = to_bhwc_uint8(images)
-    assert x.shape[1] == IMAGE and x.shape[2] == IMAGE, "oracle covers 224x224 inputs (resize is identity)"
+    assert any_size or (x.shape[1] == IMAGE and x.shape[2] == IMAGE), "oracle covers 224x224 inputs (resize is identity)"
     lut = torch.from_numpy(preprocess_lut(do_rescale, do_normalize))  # [3,256]
     idx = x.long()
     out = torch.stack([lut[c][idx[..., c]] for c in range(3)], dim=-1)
@@ -302,23 +325,53 @@ def _gelu_erf(x: torch.Tensor) -> torch.Tensor:
 
 
 def patch_matrix(pix: torch.Tensor) -> torch.Tensor:
-    """[b,224,224,3] fp32 -> [b,196,768]; K index = c*256 + ky*16 + kx; token p = py*14+px."""
-    b = pix.shape[0]
-    x = pix.view(b, GRID, PATCH, GRID, PATCH, 3)  # b py ky px kx c
+    """[b,H,W,3] fp32 -> [b,(H/16)*(W/16),768]; K index = c*256 + ky*16 + kx; token p = py*(W/16)+px."""
+    b, H, W = pix.shape[0], pix.shape[1], pix.shape[2]
+    gh, gw = H // PATCH, W // PATCH
+    x = pix.view(b, gh, PATCH, gw, PATCH, 3)  # b py ky px kx c
     x = x.permute(0, 1, 3, 5, 2, 4)  # b py px c ky kx
-    return x.reshape(b, GRID * GRID, 3 * PATCH * PATCH)
+    return x.reshape(b, gh * gw, 3 * PATCH * PATCH)
 
 
-def vit_forward(params: Dict[str, torch.Tensor], pix: torch.Tensor, backbone: str) -> torch.Tensor:
-    """fp32 [b,224,224,3] -> last_hidden_state [b,197,D] (modeling_vit.py ViTModel, pooler=Identity)."""
-    D, nh, F = ARCH[backbone]
+def interpolate_patch_pos(pos_patches: torch.Tensor, gh: int, gw: int, flavour: str) -> torch.Tensor:
+    """Bicubic interpolation of the 14x14 patch position table [196, D] to gh x gw -> [gh*gw, D] (align_corners=False).
+    flavour "size": HF ViTEmbeddings.interpolate_pos_encoding (transformers modeling_vit.py:89-127, what the reference's DeiT
+    runs): F.interpolate(size=(gh, gw)).  flavour "scale": the reference's own NoCLS / Reg embeddings (backbones.py:39-69,
+    146-177): scale_factor = ((gh + 0.1) / 14, (gw + 0.1) / 14), which samples at slightly different coordinates."""
+    D = pos_patches.shape[-1]
+    t = pos_patches.reshape(1, GRID, GRID, D).permute(0, 3, 1, 2)
+    if flavour == "size":
+        t = torch.nn.functional.interpolate(t, size=(gh, gw), mode="bicubic", align_corners=False)
+    else:
+        t = torch.nn.functional.interpolate(t, scale_factor=((gh + 0.1) / GRID, (gw + 0.1) / GRID), mode="bicubic", align_corners=False)
+        assert t.shape[-2] == gh and t.shape[-1] == gw
+    return t.permute(0, 2, 3, 1).reshape(gh * gw, D)
+
+
+def vit_forward(params: Dict[str, torch.Tensor], pix: torch.Tensor, backbone: str, interpolate_pos_encoding: bool = False) -> torch.Tensor:
+    """fp32 [b,H,W,3] -> last_hidden_state [b, ntok, D] (modeling_vit.py ViTModel, pooler=Identity).  Token layout:
+    [CLS (unless nocls-)] + patches + [7 register tokens (reg-)]  (backbones.py:71-95, 179-209)."""
+    D, nh, F = _arch(backbone)
+    _base, has_cls, nreg = backbone_variant(backbone)
     dh = D // nh
     b = pix.shape[0]
+    gh, gw = pix.shape[1] // PATCH, pix.shape[2] // PATCH
     e = "backbone.model.embeddings."
     Wp = params[e + "patch_embeddings.projection.weight"].reshape(D, -1)
     emb = patch_matrix(pix) @ Wp.t() + params[e + "patch_embeddings.projection.bias"]
-    cls = params[e + "cls_token"].expand(b, 1, D)
-    h = torch.cat([cls, emb], dim=1) + params[e + "position_embeddings"]
+    pos = params[e + "position_embeddings"][0]  # [197, D]
+    if interpolate_pos_encoding and not (gh * gw == GRID * GRID and gh == gw):
+        ppos = interpolate_patch_pos(pos[1:], gh, gw, "size" if (has_cls and nreg == 0) else "scale")
+    else:
+        assert gh == GRID and gw == GRID, "non-224 input needs interpolate_pos_encoding"
+        ppos = pos[1:]
+    toks = [emb + ppos]
+    if has_cls:
+        toks.insert(0, (params[e + "cls_token"][0] + pos[:1]).expand(b, 1, D))
+    if nreg:
+        toks.append((params[e + "reg_token"][0] + params[e + "reg_pos_embed"][0]).expand(b, nreg, D))
+    h = torch.cat(toks, dim=1)
+    NTOK = h.shape[1]  # noqa: N806 (shadows the 224-input constant inside this function)
     for i in range(NUM_LAYERS):
         p = f"backbone.model.layers.{i}."
         a = _layernorm_rows(h, params[p + "layernorm_before.weight"], params[p + "layernorm_before.bias"], LN_EPS_VIT)
@@ -428,7 +481,7 @@ def layernorm_chw(x: torch.Tensor, w_chw: torch.Tensor, b_chw: torch.Tensor, eps
     return xh * w_chw.permute(1, 2, 0) + b_chw.permute(1, 2, 0)
 
 
-def head_forward(params: Dict[str, torch.Tensor], z: torch.Tensor, teacher: str) -> torch.Tensor:
+def head_forward(params: Dict[str, torch.Tensor], z: torch.Tensor, teacher: str, backbone_no_cls: bool = False) -> torch.Tensor:
     """z [b,197,C] (final LN output incl. CLS) -> predicted teacher feature [b, Ht*Wt, Ct] (or [b, Ct] for a "_cls" head:
     one Linear on token 0, adapter_heads.py:50-57)."""
     p = f"translator.translator_heads.{head_key(teacher)}."
@@ -436,7 +489,7 @@ def head_forward(params: Dict[str, torch.Tensor], z: torch.Tensor, teacher: str)
         return z[:, 0] @ params[p + "adapter.0.weight"].t() + params[p + "adapter.0.bias"]
     Ct, Ht, Wt = MODEL_FEATURE_SIZES[teacher]
     b, _n, C = z.shape
-    x = z[:, 1:, :].reshape(b, GRID, GRID, C)  # adapter_heads.py:355-356 + Rearrange :281
+    x = (z if backbone_no_cls else z[:, 1:, :]).reshape(b, GRID, GRID, C)  # adapter_heads.py:355-356 + Rearrange :281
     # pad: ConvTranspose2d(C,C,3,stride=1,output_padding=0): 14 -> 16 (adapter_heads.py:279-290)
     x = convT3x3(x, params[p + "pad.1.weight"], params[p + "pad.1.bias"], 1, 0, 0)
     x = layernorm_chw(x, params[p + "adapter.0.weight"], params[p + "adapter.0.bias"])
@@ -456,22 +509,29 @@ def head_forward(params: Dict[str, torch.Tensor], z: torch.Tensor, teacher: str)
     return x @ params[p + "adapter.8.weight"].t() + params[p + "adapter.8.bias"]
 
 
-def translator_forward(params, z, teachers: Sequence[str]) -> "Dict[str, torch.Tensor]":
-    return {t: head_forward(params, z, t) for t in teachers}
+def translator_forward(params, z, teachers: Sequence[str], backbone_no_cls: bool = False) -> "Dict[str, torch.Tensor]":
+    return {t: head_forward(params, z, t, backbone_no_cls) for t in teachers}
 
 
 # ----------------------------------------------------------------------------------------
 # a6, a7: model entry points (models/rvfm.py:94-136)
 # ----------------------------------------------------------------------------------------
 def forward_feature(params, images, backbone: str, feature_reduce_method: Optional[str] = None,
-                    do_rescale: bool = True, do_normalize: bool = True) -> torch.Tensor:
-    z = vit_forward(params, preprocess(images, do_rescale, do_normalize), backbone)
-    return handle_feature_output(z, feature_reduce_method, 0)
+                    do_rescale: bool = True, do_normalize: bool = True, interpolate_pos_encoding: bool = False) -> torch.Tensor:
+    """models/rvfm.py:94-113.  Note the reference slices x[:, 1:n-disc] whatever the backbone: a nocls- student loses its
+    first patch token here (195 tokens) -- reproduced, not fixed."""
+    z = vit_forward(params, preprocess(images, do_rescale, do_normalize, any_size=interpolate_pos_encoding), backbone,
+                    interpolate_pos_encoding)
+    return handle_feature_output(z, feature_reduce_method, backbone_variant(backbone)[2])
 
 
 def forward(params, images, backbone: str, teachers: Sequence[str]) -> "Dict[str, torch.Tensor]":
+    """models/rvfm.py:115-136: register tokens are stripped before the translator (:133-134)."""
     z = vit_forward(params, preprocess(images), backbone)
-    return translator_forward(params, z, teachers)
+    _base, has_cls, nreg = backbone_variant(backbone)
+    if nreg:
+        z = z[:, :-nreg]
+    return translator_forward(params, z, teachers, backbone_no_cls=not has_cls)
 
 
 # ----------------------------------------------------------------------------------------

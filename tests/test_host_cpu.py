@@ -51,3 +51,57 @@ def test_bench_multi_gpu_request_enters_the_launcher():
     assert r.returncode == 2, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["value"] is None and line["n_gpus"] == 2 and "GPU" in line["error"]
+
+
+def test_hub_style_loader_round_trip_and_legacy_keys(tmp_path):
+    """theia_amd.hub.TheiaModel: save_pretrained -> from_pretrained on a hub-layout directory (config.json + model.safetensors),
+    a checkpoint with transformers-4.4x-era key names + foreign keys (weight filter of rvfm.py:77-87), and AutoModel dispatch."""
+    import torch
+    from oracle import theia_oracle as O
+    from theia_amd.foundation_models.common import get_model_feature_size
+    from theia_amd.hub import TheiaModel, register_with_transformers
+    bb, teachers = "facebook/deit-tiny-patch16-224", O.TEACHER_SETS["cdiv"]
+    m = TheiaModel(backbone=bb, translator="lconv", translator_kwargs={"hidden_size_factor": 1.0}, feature_reduce_method="cls",
+                   target_feature_sizes={t: get_model_feature_size(t, keep_spatial=True) for t in teachers})
+    m.load_state_dict(O.synth_params(bb, teachers, 0), strict=True)
+    m.save_pretrained(str(tmp_path / "snap"))
+    assert sorted(os.listdir(tmp_path / "snap")) == ["config.json", "model.safetensors"]
+    m2 = TheiaModel.from_pretrained(str(tmp_path / "snap"))
+    assert m2.feature_reduce_method == "cls" and list(m2.target_feature_sizes) == teachers and m2.loading_info["missing_keys"] == []
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+    # keyword overrides like AutoModel.from_pretrained(..., feature_reduce_method=...)
+    assert TheiaModel.from_pretrained(str(tmp_path / "snap"), feature_reduce_method=None).feature_reduce_method is None
+    # 4.4x-era names + keys the model does not have
+    legacy = {}
+    for k, v in m.state_dict().items():
+        k2 = (k.replace(".layers.", ".encoder.layer.").replace(".attention.q_proj.", ".attention.attention.query.")
+               .replace(".attention.k_proj.", ".attention.attention.key.").replace(".attention.v_proj.", ".attention.attention.value.")
+               .replace(".attention.o_proj.", ".attention.output.dense.").replace(".mlp.fc1.", ".intermediate.dense.")
+               .replace(".mlp.fc2.", ".output.dense."))
+        legacy[k2] = v.clone()
+    legacy["backbone.model.pooler.dense.weight"] = torch.zeros(4, 4)
+    os.makedirs(tmp_path / "old")
+    torch.save(legacy, tmp_path / "old" / "pytorch_model.bin")
+    json.dump({"backbone": bb, "target_model_names": teachers}, open(tmp_path / "old" / "config.json", "w"))
+    m3 = TheiaModel.from_pretrained(str(tmp_path / "old"))
+    assert m3.loading_info["missing_keys"] == [] and m3.loading_info["unexpected_keys"] == 1
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m3.state_dict()[k]), k
+    register_with_transformers()
+    from transformers import AutoModel
+    m4 = AutoModel.from_pretrained(str(tmp_path / "snap"))
+    assert isinstance(m4, TheiaModel) and torch.equal(m4.state_dict()["backbone.model.layernorm.weight"], m.state_dict()["backbone.model.layernorm.weight"])
+
+
+def test_backbone_variants_build_with_reference_parameter_names():
+    from oracle import theia_oracle as O
+    from theia_amd.models.rvfm import RobotVisionFM
+    for name, ntok in (("nocls-facebook/deit-tiny-patch16-224", 196), ("reg-facebook/deit-tiny-patch16-224", 204), ("facebook/deit-tiny-patch16-224", 197)):
+        m = RobotVisionFM(backbone=name, translator="lconv", translator_kwargs={"hidden_size_factor": 1.0}, target_feature_sizes=None)
+        assert sorted(k for k in m.state_dict()) == sorted(k for k in O.param_shapes(name, []))
+        for k, shp in O.param_shapes(name, []).items():
+            assert tuple(m.state_dict()[k].shape) == tuple(shp), k
+        assert m.engine.geo224.ntok == ntok and m.no_cls == name.startswith("nocls") and m.num_reg_tokens == (7 if name.startswith("reg") else 0)
+    m = RobotVisionFM(backbone="reg-facebook/deit-tiny-patch16-224", translator="lconv", target_feature_sizes=None, num_reg_tokens=4)
+    assert m.num_reg_tokens == 4 and m.state_dict()["backbone.model.embeddings.reg_token"].shape == (1, 4, 192)

@@ -366,3 +366,73 @@ def test_forward_feature_is_differentiable_for_every_reduce_mode():
         (ref * w).sum().backward()
         want = dict(model.named_parameters())[probe].grad
         assert torch.allclose(got, want, rtol=1e-4, atol=1e-7), mode
+
+
+@pytest.mark.parametrize("key", ["g15", "g16"])
+def test_nocls_and_reg_students_match_reference_goldens(golden_dir, key):
+    """The student without CLS token (196 tokens, backbones.py:344-416) and the one with 7 register tokens (204 tokens,
+    :419-503) against the reference's own classes (goldens G15 / G16: features, predictions, losses, every gradient norm).
+    forward_feature of the nocls- student returns 195 tokens: the reference slices x[:, 1:] whatever the backbone."""
+    name = {"g15": "g15_nocls_tiny_dinov2_b2.npz", "g16": "g16_reg_tiny_dinov2_b2.npz"}[key]
+    g = np.load(os.path.join(golden_dir, name))
+    bb, teachers, B = str(g["meta_backbone"]), [str(t) for t in g["meta_teachers"]], int(g["meta_B"])
+    model, _ = build(bb, teachers, "fp32")
+    assert model.no_cls == (key == "g15") and model.num_reg_tokens == (7 if key == "g16" else 0)
+    assert sorted(model.state_dict().keys()) == sorted(str(n) for n in g["grad_names"])
+    images = O.synth_images(B, 0)
+    targets = {t: v.to("cuda:0") for t, v in O.synth_targets(B, teachers, 1).items()}
+    with torch.no_grad():
+        feat = model.forward_feature(images)
+    assert tuple(feat.shape) == tuple(g["feat_shape"])
+    f = feat.float().cpu().numpy().reshape(-1)
+    assert np.abs(f[g["feat_idx"]] - g["feat_val"]).max() / np.abs(g["feat_val"]).max() < 1e-4
+    assert rel(np.abs(f.astype(np.float64)).sum(), float(g["feat_abssum"])) < 1e-5
+    pred = model(images)
+    for ti, t in enumerate(teachers):
+        p = pred[t].detach().float().cpu().numpy().reshape(-1)
+        assert np.abs(p[g[f"pred{ti}_idx"]] - g[f"pred{ti}_val"]).max() / np.abs(g[f"pred{ti}_val"]).max() < 1e-4
+    losses = model.get_loss(pred, targets)
+    for k in ("mse_loss", "cos_loss", "l1_loss"):
+        assert rel(float(losses[k]), float(g[k])) < 1e-4, k
+    (0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]).backward()
+    sdp = dict(model.named_parameters())
+    for i, k in enumerate(str(n) for n in g["grad_names"]):
+        gn = float(sdp[k].grad.double().pow(2).sum().sqrt())
+        if "k_proj.bias" in k:
+            assert gn < 1e-6 * max(1.0, g["gradnorm_cos_l1"].max()), k
+            continue
+        assert rel(gn, g["gradnorm_cos_l1"][i]) < 1e-3, (k, gn, g["gradnorm_cos_l1"][i])
+    # the throughput mode on the same students
+    mb, params = build(bb, teachers, "bf16")
+    lb = mb.get_loss(mb(images), targets)
+    for k in ("mse_loss", "cos_loss", "l1_loss"):
+        assert rel(float(lb[k]), float(g[k])) < 2e-2, k
+
+
+@pytest.mark.parametrize("tag,bb", [("deit", "facebook/deit-tiny-patch16-224"), ("nocls", "nocls-facebook/deit-tiny-patch16-224"),
+                                    ("reg", "reg-facebook/deit-tiny-patch16-224")])
+def test_interpolated_position_embeddings_match_reference(golden_dir, tag, bb):
+    """160x192 images with do_resize=False, interpolate_pos_encoding=True (120 patch tokens) against the reference (golden
+    G17): features, and the gradients through the bicubic interpolation into position_embeddings, a mid-depth weight and the
+    patch projection.  DeiT uses HF's size-based interpolation, nocls- / reg- the reference's own scale_factor variant."""
+    g = np.load(os.path.join(golden_dir, "g17_interpolate_pos.npz"))
+    model, _ = build(bb, O.TEACHER_SETS["dinov2"], "fp32")
+    img = torch.from_numpy(g["img"])
+    with pytest.raises(ValueError, match="doesn't match model"):
+        model.forward_feature(img, do_resize=False)
+    z = model.forward_feature(img, do_resize=False, interpolate_pos_encoding=True)
+    assert tuple(z.shape) == tuple(g[f"{tag}_z_shape"])
+    zz = z.detach().float().cpu().numpy().reshape(-1)
+    assert np.abs(zz[g[f"{tag}_z_idx"]] - g[f"{tag}_z_val"]).max() / np.abs(g[f"{tag}_z_val"]).max() < 1e-4
+    assert rel(np.abs(zz.astype(np.float64)).sum(), float(g[f"{tag}_z_abssum"])) < 1e-5
+    w = torch.from_numpy(O._hash_uniform(z.numel(), 77).reshape(tuple(z.shape)).copy()).to(z.device)
+    (z * w).sum().backward()
+    sdp = dict(model.named_parameters())
+    for short, k in (("pos", "backbone.model.embeddings.position_embeddings"), ("fc1", "backbone.model.layers.3.mlp.fc1.weight"),
+                     ("patch", "backbone.model.embeddings.patch_embeddings.projection.weight")):
+        gr = sdp[k].grad.detach().float().cpu().numpy().reshape(-1)
+        assert rel(float(np.sqrt((gr.astype(np.float64) ** 2).sum())), float(g[f"{tag}_g{short}_norm"])) < 1e-3, (tag, short)
+        assert np.abs(gr[g[f"{tag}_g{short}_idx"]] - g[f"{tag}_g{short}_val"]).max() <= 1e-2 * float(g[f"{tag}_g{short}_norm"]) / np.sqrt(gr.size) + 1e-9
+    # same images through the default path (processor resize to 224): 196 patch tokens again
+    with torch.no_grad():
+        assert model.forward_feature(img).shape[1] == (195 if tag == "nocls" else 196)

@@ -16,7 +16,8 @@ def rel(a, b):
     return abs(a - b) / (abs(b) + 1e-30)
 
 
-@pytest.mark.parametrize("name", ["g1_tiny_dinov2_b8", "g2_tiny_cdiv_b2", "g3_tiny_cddsv_b2", "g4_small_cddsv_b1", "g13_tiny_dinov2_cls_b2"])
+@pytest.mark.parametrize("name", ["g1_tiny_dinov2_b8", "g2_tiny_cdiv_b2", "g3_tiny_cddsv_b2", "g4_small_cddsv_b1", "g13_tiny_dinov2_cls_b2",
+                                  "g15_nocls_tiny_dinov2_b2", "g16_reg_tiny_dinov2_b2"])
 def test_oracle_matches_reference_goldens(golden_dir, name):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     bb, teachers, B = str(g["meta_backbone"]), [str(t) for t in g["meta_teachers"]], int(g["meta_B"])
@@ -41,6 +42,28 @@ def test_oracle_matches_reference_goldens(golden_dir, name):
             assert gn < 1e-6
             continue
         assert rel(gn, g["gradnorm_cos_l1"][i]) < 1e-3, k  # fp32 summation-order noise on tiny norms
+
+
+G17_CASES = (("deit", "facebook/deit-tiny-patch16-224"), ("nocls", "nocls-facebook/deit-tiny-patch16-224"), ("reg", "reg-facebook/deit-tiny-patch16-224"))
+
+
+@pytest.mark.parametrize("tag,bb", G17_CASES)
+def test_oracle_interpolated_position_embeddings_g17(golden_dir, tag, bb):
+    """160x192 inputs, do_resize=False + interpolate_pos_encoding=True, on the reference (golden G17): features and the
+    gradients that flow through the bicubic interpolation into position_embeddings (both interpolation flavours)."""
+    g = np.load(os.path.join(golden_dir, "g17_interpolate_pos.npz"))
+    params = {k: v.clone().requires_grad_(True) for k, v in O.synth_params(bb, O.TEACHER_SETS["dinov2"], 0).items()}
+    z = O.forward_feature(params, torch.from_numpy(g["img"]), bb, interpolate_pos_encoding=True)
+    assert tuple(z.shape) == tuple(g[f"{tag}_z_shape"])
+    zz = z.detach().numpy().reshape(-1)
+    assert np.abs(zz[g[f"{tag}_z_idx"]] - g[f"{tag}_z_val"]).max() / np.abs(g[f"{tag}_z_val"]).max() < 1e-5
+    assert rel(np.abs(zz.astype(np.float64)).sum(), float(g[f"{tag}_z_abssum"])) < 1e-6
+    w = torch.from_numpy(O._hash_uniform(z.numel(), 77).reshape(tuple(z.shape)).copy())
+    (z * w).sum().backward()
+    for short, k in (("pos", "backbone.model.embeddings.position_embeddings"), ("fc1", "backbone.model.layers.3.mlp.fc1.weight"),
+                     ("patch", "backbone.model.embeddings.patch_embeddings.projection.weight")):
+        gr = params[k].grad.numpy().reshape(-1)
+        assert rel(float(np.sqrt((gr.astype(np.float64) ** 2).sum())), float(g[f"{tag}_g{short}_norm"])) < 1e-3, (tag, short)
 
 
 def test_oracle_micro_ops_g10(golden_dir):

@@ -92,7 +92,9 @@ _SIGNATURES = {
     "theia_unpermute3_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64,
                                        C.c_int, C.c_void_p]),
     "theia_patchify_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "theia_patchify_u8_hw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "theia_write_cls": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "theia_write_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "theia_layernorm_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "theia_layernorm_bwd": (C.c_int, [C.c_void_p] * 10 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "theia_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),

@@ -291,66 +291,84 @@ extern "C" int theia_resize_u8(const uint8_t* src, uint8_t* dst, uint8_t* tmp, i
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void patchify_kernel(const uint8_t* __restrict__ img, const float* __restrict__ lut,
-                                                       T* __restrict__ out, int b, int channels_last) {
+                                                       T* __restrict__ out, int b, int H, int W, int channels_last) {
     __shared__ float slut[768];
     for (int i = threadIdx.x; i < 768; i += 256) slut[i] = lut[i];
     __syncthreads();
-    const int64_t nvec = (int64_t)b * 196 * 96;  // 768/8 vectors per row
+    const int gh = H / 16, gw = W / 16, P = gh * gw;  // pixels beyond the last whole patch are not read (Conv2d stride 16)
+    const int64_t nvec = (int64_t)b * P * 96;  // 768/8 vectors per row
     for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
         const int cv = (int)(v % 96);
         const int64_t row = v / 96;
-        const int p = (int)(row % 196), bi = (int)(row / 196);
-        const int py = p / 14, px = p - py * 14;
+        const int p = (int)(row % P), bi = (int)(row / P);
+        const int py = p / gw, px = p - py * gw;
         const int k = cv * 8;
         const int c = k >> 8, ky = (k >> 4) & 15, kx = k & 15;
         const int y = py * 16 + ky, x = px * 16 + kx;
         float o[8];
         if (channels_last) {
-            const uint8_t* src = img + (((int64_t)bi * 224 + y) * 224 + x) * 3 + c;
+            const uint8_t* src = img + (((int64_t)bi * H + y) * W + x) * 3 + c;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = slut[c * 256 + src[3 * j]];
         } else {
-            const uint8_t* src = img + (((int64_t)bi * 3 + c) * 224 + y) * 224 + x;
-            const uint2 w = *reinterpret_cast<const uint2*>(src);  // 8-byte aligned: x % 8 == 0
+            const uint8_t* src = img + (((int64_t)bi * 3 + c) * H + y) * W + x;
+            if ((W & 7) == 0) {  // x % 8 == 0 and rows 8-byte aligned: one vector load
+                const uint2 w = *reinterpret_cast<const uint2*>(src);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[j] = slut[c * 256 + ((w.x >> (8 * j)) & 0xff)];
-                o[4 + j] = slut[c * 256 + ((w.y >> (8 * j)) & 0xff)];
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = slut[c * 256 + ((w.x >> (8 * j)) & 0xff)];
+                    o[4 + j] = slut[c * 256 + ((w.y >> (8 * j)) & 0xff)];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = slut[c * 256 + src[j]];
             }
         }
         store8(out + row * 768 + k, o);
     }
 }
-extern "C" int theia_patchify_u8(const uint8_t* img, const float* lut, void* out, int b, int channels_last, int dtype,
-                                 void* stream) {
-    THEIA_CHECK_ARG(img && lut && out && b > 0, "theia_patchify_u8: bad args");
+extern "C" int theia_patchify_u8_hw(const uint8_t* img, const float* lut, void* out, int b, int H, int W, int channels_last,
+                                    int dtype, void* stream) {
+    THEIA_CHECK_ARG(img && lut && out && b > 0 && H >= 16 && W >= 16, "theia_patchify_u8: bad args (b=%d H=%d W=%d)", b, H, W);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int g = grid_for((int64_t)b * 196 * 96, 256, 16384);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(g), dim3(256), 0, s, img, lut, (bf16_t*)out, b, channels_last),
-               hipLaunchKernelGGL(patchify_kernel<float>, dim3(g), dim3(256), 0, s, img, lut, (float*)out, b, channels_last),
+    const int g = grid_for((int64_t)b * (H / 16) * (W / 16) * 96, 256, 16384);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(g), dim3(256), 0, s, img, lut, (bf16_t*)out, b, H, W, channels_last),
+               hipLaunchKernelGGL(patchify_kernel<float>, dim3(g), dim3(256), 0, s, img, lut, (float*)out, b, H, W, channels_last),
                "theia_patchify_u8");
     THEIA_CHECK_LAUNCH("theia_patchify_u8");
     return THEIA_OK;
 }
+extern "C" int theia_patchify_u8(const uint8_t* img, const float* lut, void* out, int b, int channels_last, int dtype,
+                                 void* stream) {
+    return theia_patchify_u8_hw(img, lut, out, b, 224, 224, channels_last, dtype, stream);
+}
 
+// h[b, t0 + r, :] = tok[r, :] + pos[r, :] for r < cnt: the CLS token (t0 = 0, cnt = 1) and the register tokens of the reg-
+// students (t0 = 1 + patches, cnt = 7; reference backbones.py:196-205)
 template <typename T>
-__global__ void write_cls_kernel(const float* __restrict__ cls, const float* __restrict__ pos, T* __restrict__ h, int b,
-                                 int ntok, int D) {
-    const int64_t n = (int64_t)b * D;
+__global__ void write_tokens_kernel(const float* __restrict__ tok, const float* __restrict__ pos, T* __restrict__ h, int b,
+                                    int ntok, int t0, int cnt, int D) {
+    const int64_t n = (int64_t)b * cnt * D;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int d = (int)(i % D);
-        const int64_t bi = i / D;
-        Elem<T>::st(h + bi * ntok * D + d, cls[d] + pos[d]);
+        const int r = (int)((i / D) % cnt);
+        const int64_t bi = i / ((int64_t)D * cnt);
+        Elem<T>::st(h + (bi * ntok + t0 + r) * D + d, tok[r * D + d] + pos[r * D + d]);
     }
 }
-extern "C" int theia_write_cls(const float* cls, const float* pos, void* h, int b, int ntok, int D, int dtype, void* stream) {
-    THEIA_CHECK_ARG(cls && pos && h && b > 0 && D > 0, "theia_write_cls: bad args");
+extern "C" int theia_write_tokens(const float* tok, const float* pos, void* h, int b, int ntok, int t0, int cnt, int D, int dtype,
+                                  void* stream) {
+    THEIA_CHECK_ARG(tok && pos && h && b > 0 && D > 0 && cnt > 0 && t0 >= 0 && t0 + cnt <= ntok, "theia_write_tokens: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int g = grid_for((int64_t)b * D, 256, 4096);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(write_cls_kernel<bf16_t>, dim3(g), dim3(256), 0, s, cls, pos, (bf16_t*)h, b, ntok, D),
-               hipLaunchKernelGGL(write_cls_kernel<float>, dim3(g), dim3(256), 0, s, cls, pos, (float*)h, b, ntok, D), "theia_write_cls");
-    THEIA_CHECK_LAUNCH("theia_write_cls");
+    const int g = grid_for((int64_t)b * cnt * D, 256, 4096);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(write_tokens_kernel<bf16_t>, dim3(g), dim3(256), 0, s, tok, pos, (bf16_t*)h, b, ntok, t0, cnt, D),
+               hipLaunchKernelGGL(write_tokens_kernel<float>, dim3(g), dim3(256), 0, s, tok, pos, (float*)h, b, ntok, t0, cnt, D),
+               "theia_write_tokens");
+    THEIA_CHECK_LAUNCH("theia_write_tokens");
     return THEIA_OK;
+}
+extern "C" int theia_write_cls(const float* cls, const float* pos, void* h, int b, int ntok, int D, int dtype, void* stream) {
+    return theia_write_tokens(cls, pos, h, b, ntok, 0, 1, D, dtype, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ import torch
 
 from . import _native as N
 from . import ops
-from .models.backbones import GRID, IMAGE, NTOK, NUM_LAYERS
+from .models.backbones import GRID, IMAGE, MAX_TOKENS, NUM_LAYERS
 
 # bumped by optimizers that update parameters through raw pointers (torch's version counter does not see those)
 PARAM_EPOCH = [0]
@@ -82,6 +82,38 @@ def to_uint8_batch(x: Any, any_size: bool = False):
     if not any_size and (hh != IMAGE or ww != IMAGE):
         raise NotImplementedError(f"{hh}x{ww} input: feed {IMAGE}x{IMAGE} images")
     return x.contiguous(), channels_last
+
+
+class Geometry:
+    """Token layout of one forward pass: [CLS (tok0 = 1) | gh*gw patch tokens | nreg register tokens]."""
+
+    def __init__(self, gh: int, gw: int, tok0: int, nreg: int, interp: bool):
+        self.gh, self.gw, self.P, self.tok0, self.nreg, self.interp = gh, gw, gh * gw, tok0, nreg, interp
+        self.ntok = tok0 + self.P + nreg
+        self.key = (gh, gw, tok0, nreg, interp)
+
+
+def bicubic_matrix(n_in: int, n_out: int, scale: float) -> np.ndarray:
+    """[n_out, n_in] f32 matrix of torch's upsample_bicubic (align_corners=False, A = -0.75) along one axis, in its f32
+    arithmetic: source coordinate scale*(dst + 0.5) - 0.5, 4 taps at floor-1 .. floor+2 with indices clamped to the border.
+    (torch/aten UpSampleBicubic2d / UpSample.h cubic_convolution1/2.)"""
+    A = np.float32(-0.75)
+    m = np.zeros((n_out, n_in), dtype=np.float32)
+    for o in range(n_out):
+        real = np.float32(scale) * (np.float32(o) + np.float32(0.5)) - np.float32(0.5)
+        i0 = int(np.floor(real))
+        t = np.float32(real - np.float32(i0))
+
+        def c1(x):
+            return ((A + np.float32(2)) * x - (A + np.float32(3))) * x * x + np.float32(1)
+
+        def c2(x):
+            return ((A * x - np.float32(5) * A) * x + np.float32(8) * A) * x - np.float32(4) * A
+
+        w = [c2(t + np.float32(1)), c1(t), c1(np.float32(1) - t), c2(np.float32(2) - t)]
+        for k in range(4):
+            m[o, min(max(i0 - 1 + k, 0), n_in - 1)] += w[k]
+    return m
 
 
 class _SideQueue:
@@ -197,6 +229,9 @@ class StudentEngine:
         self.precision = precision
         vit = rvfm.backbone.model
         self.D, self.heads, self.F = vit.hidden_size, vit.num_heads, vit.intermediate_size
+        self.tok0, self.nreg = (1 if vit.has_cls else 0), vit.num_reg_tokens  # token layout of the student (nocls- / reg-)
+        self.geo224 = Geometry(GRID, GRID, self.tok0, self.nreg, False)
+        self._interp: Dict[Any, Any] = {}
         self._opcache: Dict[str, torch.Tensor] = {}
         self._opkey = None
         self._op_ptr_key = None
@@ -290,22 +325,51 @@ class StudentEngine:
             self._luts[k] = t
         return t
 
-    def _plan(self, key: str):
-        if key not in self._plans:
-            C = self.D
-            if key == "pad":
-                self._plans[key] = ops.plan_convT3x3(C, GRID, 1, 0, 0, in_bs=NTOK * C, in_off=C)
+    def _plan(self, key: str, geo: Optional[Geometry] = None):
+        geo = geo or self.geo224
+        ck = key if key in ("conv16", "up31", "up64") else (key,) + geo.key
+        if ck not in self._plans:
+            C, D = self.D, self.D
+            if key == "pad":  # reads the 14x14 patch tokens of z[b, ntok, C] in place: rows tok0 .. tok0+195 of every image
+                self._plans[ck] = ops.plan_convT3x3(C, GRID, 1, 0, 0, in_bs=geo.ntok * C, in_off=geo.tok0 * C)
             elif key == "conv16":
-                self._plans[key] = ops.plan_conv3x3(C, 16)
+                self._plans[ck] = ops.plan_conv3x3(C, 16)
             elif key == "up31":
-                self._plans[key] = ops.plan_convT3x3(C, 16, 2, 1, 0)
+                self._plans[ck] = ops.plan_convT3x3(C, 16, 2, 1, 0)
             elif key == "up64":
-                self._plans[key] = ops.plan_convT3x3(C, 31, 2, 0, 1)
-            elif key == "patch":
-                D = self.D
-                self._plans[key] = ops.rowmap([(0, 0, 0)], (GRID, GRID), (GRID, GRID), 1, 768, GRID * GRID * 768, 0, GRID, 1, 0, 0,
-                                              NTOK * D, D)
-        return self._plans[key]
+                self._plans[ck] = ops.plan_convT3x3(C, 31, 2, 0, 1)
+            elif key == "patch":  # [b*P, 768] patch matrix -> token rows tok0 + p of h[b, ntok, D]
+                self._plans[ck] = ops.rowmap([(0, 0, 0)], (geo.gh, geo.gw), (geo.gh, geo.gw), 1, 768, geo.P * 768, 0, geo.gw, 1, 0, 0,
+                                             geo.ntok * D, geo.tok0 * D)
+        return self._plans[ck]
+
+    # ------------------------------------------------------------------ position embeddings on another patch grid
+    def _interp_mats(self, geo: Geometry, device):
+        """(W [P, 196], W^T zero-padded to [196, P4]) f32 on the device: the bicubic interpolation of the 14x14 position table
+        to gh x gw as ONE matrix (the op is linear in the table).  DeiT: HF's F.interpolate(size=(gh, gw)) (transformers
+        modeling_vit.py:89-127); nocls- / reg-: the reference's scale_factor = (g + 0.1) / 14 variant (backbones.py:39-69,146-177)."""
+        k = (geo.gh, geo.gw, device)
+        if k not in self._interp:
+            own = self.tok0 == 0 or self.nreg > 0
+            sy = 1.0 / ((geo.gh + 0.1) / GRID) if own else GRID / geo.gh
+            sx = 1.0 / ((geo.gw + 0.1) / GRID) if own else GRID / geo.gw
+            wy, wx = bicubic_matrix(GRID, geo.gh, sy), bicubic_matrix(GRID, geo.gw, sx)
+            w = np.einsum("ai,bj->abij", wy, wx).reshape(geo.P, GRID * GRID).astype(np.float32)
+            p4 = (geo.P + 3) // 4 * 4
+            wt = np.zeros((GRID * GRID, p4), dtype=np.float32)
+            wt[:, :geo.P] = w.T
+            self._interp[k] = (torch.from_numpy(w).to(device), torch.from_numpy(wt).to(device), p4)
+        return self._interp[k]
+
+    def _patch_pos(self, geo: Geometry, device) -> torch.Tensor:
+        """f32 [P, D]: the position rows added to the patch tokens"""
+        pos = self.rvfm.backbone.model.embeddings.position_embeddings.view(GRID * GRID + 1, self.D)
+        if not geo.interp:
+            return pos[1:]
+        w, _wt, _p4 = self._interp_mats(geo, device)
+        posT = torch.empty(self.D, GRID * GRID, dtype=torch.float32, device=device)
+        ops.cast_transpose(pos[1:], posT)
+        return ops.linear(w, posT)  # exact-f32 MFMA path: [P, 196] @ [196, D]
 
     # ------------------------------------------------------------------ operand cache
     def _operands(self, device) -> Dict[str, torch.Tensor]:
@@ -376,23 +440,32 @@ class StudentEngine:
         return oc, cb
 
     # ================================================================== backbone
-    def backbone(self, x: Any, do_rescale: bool = True, do_normalize: bool = True, do_resize: bool = True) -> torch.Tensor:
+    def backbone(self, x: Any, do_rescale: bool = True, do_normalize: bool = True, do_resize: bool = True,
+                 interpolate_pos_encoding: bool = False) -> torch.Tensor:
         vit = self.rvfm.backbone.model
         device = vit.layernorm.weight.device
         if device.type != "cuda":
             raise RuntimeError("theia_amd runs on a ROCm GPU only: move the model with .to('cuda') (no CPU fallback)")
         batch = to_uint8_batch(x, any_size=True)
-        img, channels_last = self._to_model_size(batch, device, do_resize)
+        img, channels_last = self._to_model_size(batch, device, do_resize, interpolate_pos_encoding)
+        hh, ww = (img.shape[1], img.shape[2]) if channels_last else (img.shape[2], img.shape[3])
+        gh, gw = hh // 16, ww // 16
+        # HF interpolates unless the patch count matches the table and the image is square (modeling_vit.py:103-104)
+        interp = interpolate_pos_encoding and not (gh * gw == GRID * GRID and hh == ww)
+        geo = self.geo224 if (gh, gw, interp) == (GRID, GRID, False) else Geometry(gh, gw, self.tok0, self.nreg, interp)
+        if geo.ntok > MAX_TOKENS:
+            raise NotImplementedError(f"{hh}x{ww} input = {geo.ntok} tokens: the attention kernels hold at most {MAX_TOKENS}")
         params = list(vit.parameters())
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            return _BackboneFn.apply(self, img, channels_last, do_rescale, do_normalize, *params)
-        z, _ = self._backbone_fwd(img, channels_last, do_rescale, do_normalize, save=False)
+            return _BackboneFn.apply(self, img, channels_last, do_rescale, do_normalize, geo, *params)
+        z, _ = self._backbone_fwd(img, channels_last, do_rescale, do_normalize, save=False, geo=geo)
         return z
 
-    def _to_model_size(self, batch, device, do_resize: bool = True) -> Tuple[torch.Tensor, bool]:
+    def _to_model_size(self, batch, device, do_resize: bool = True, any_final_size: bool = False) -> Tuple[torch.Tensor, bool]:
         """The processor's resize and center-crop steps (backbones.py:337-339; order resize -> crop as in the HF processor):
         theia_resize_u8 (Pillow's resampling, bit-exact) on the GPU to the configured size when do_resize, then the
-        center crop (top = (H - crop) // 2).  Images already at the final size pass through untouched."""
+        center crop (top = (H - crop) // 2).  Images already at the final size pass through untouched.  any_final_size:
+        interpolate_pos_encoding was requested, the student runs at whatever size comes out."""
         bb = self.rvfm.backbone
         (rh, rw), crop, resample = bb.resize_size, bb.crop_size, bb.resample
 
@@ -407,9 +480,11 @@ class StudentEngine:
                 top, left = (hh - crop) // 2, (ww - crop) // 2
                 t = t[:, top:top + crop, left:left + crop, :] if cl else t[:, :, top:top + crop, left:left + crop]
                 hh = ww = crop
-            if (hh, ww) != (IMAGE, IMAGE):
-                raise NotImplementedError(f"{hh}x{ww} after the processor: position-embedding interpolation is outside the hot "
-                                          f"path (SURVEY.md sec. 8f-3); feed {IMAGE}x{IMAGE} images or keep do_resize=True")
+            if (hh, ww) != (IMAGE, IMAGE) and not any_final_size:  # HF ViTEmbeddings.forward raises the same way (modeling_vit.py:152-157)
+                raise ValueError(f"Input image size ({hh}*{ww}) doesn't match model ({IMAGE}*{IMAGE}): keep do_resize=True or pass "
+                                 f"interpolate_pos_encoding=True")
+            if hh < 16 or ww < 16:
+                raise ValueError(f"{hh}x{ww} image: smaller than one 16x16 patch")
             return t, cl
 
         if isinstance(batch, list):  # items of different sizes: one resize launch per item, then one batch
@@ -417,25 +492,33 @@ class StudentEngine:
             for t, cl in batch:
                 t, cl = one(t, cl)
                 outs.append(t if cl else t.permute(0, 2, 3, 1))
+            if len({tuple(o.shape[1:]) for o in outs}) > 1:
+                raise ValueError("images of different sizes after the processor cannot be batched")
             return torch.cat(outs, 0).contiguous(), True
         img, cl = one(*batch)
         return img.contiguous(), cl
 
-    def _backbone_fwd(self, img: torch.Tensor, channels_last: bool, do_rescale: bool, do_normalize: bool, save: bool):
+    def _backbone_fwd(self, img: torch.Tensor, channels_last: bool, do_rescale: bool, do_normalize: bool, save: bool,
+                      geo: Optional[Geometry] = None):
+        geo = geo or self.geo224
         dev, T, D, F, nh = img.device, self.dtype, self.D, self.F, self.heads
+        NTOK, P = geo.ntok, geo.P
         oc = self._operands(dev)
         vit = self.rvfm.backbone.model
         emb = vit.embeddings
         b = img.shape[0]
         M = b * NTOK
-        patches = torch.empty(b * GRID * GRID, 768, dtype=T, device=dev)
+        patches = torch.empty(b * P, 768, dtype=T, device=dev)
         ops.patchify(img, self._lut(do_rescale, do_normalize, dev), patches, channels_last)
         h = torch.empty(M, D, dtype=T, device=dev)
-        pos = emb.position_embeddings
-        ops.gemm_nt(patches, oc["patch.w"], h, b * GRID * GRID, D, 768, self._plan("patch"), 768, D,
-                    bias=emb.patch_embeddings.projection.bias, rowtab=pos.view(NTOK, D)[1:], rowtab_period=GRID * GRID)
-        ops.write_cls(emb.cls_token, pos, h, b, NTOK, D)
-        saved: Dict[str, Any] = {"b": b, "patches": patches if save else None, "layers": []}
+        pos = emb.position_embeddings.view(GRID * GRID + 1, D)
+        ops.gemm_nt(patches, oc["patch.w"], h, b * P, D, 768, self._plan("patch", geo), 768, D,
+                    bias=emb.patch_embeddings.projection.bias, rowtab=self._patch_pos(geo, dev), rowtab_period=P)
+        if geo.tok0:  # CLS token + its position row (modeling_vit.py:148-149,159)
+            ops.write_tokens(emb.cls_token.view(1, D), pos[:1], h, b, NTOK, 0, 1, D)
+        if geo.nreg:  # register tokens + their own position rows, after the patches (backbones.py:196-205)
+            ops.write_tokens(emb.reg_token.view(geo.nreg, D), emb.reg_pos_embed.view(geo.nreg, D), h, b, NTOK, geo.tok0 + P, geo.nreg, D)
+        saved: Dict[str, Any] = {"b": b, "geo": geo, "patches": patches if save else None, "layers": []}
         for i, L in enumerate(vit.layers):
             a, mean1, rstd1 = ops.layernorm_fwd(h, L.layernorm_before.weight, L.layernorm_before.bias, LN_EPS_VIT)
             qkv = ops.linear(a, oc[f"l{i}.wqkv"], oc[f"l{i}.bqkv"])
@@ -457,7 +540,8 @@ class StudentEngine:
         dev, T, D, F, nh = dz.device, self.dtype, self.D, self.F, self.heads
         oc = self._operands(dev)
         vit = self.rvfm.backbone.model
-        b = saved["b"]
+        b, geo = saved["b"], saved["geo"]
+        NTOK, P = geo.ntok, geo.P
         M = b * NTOK
         dz = dz.contiguous().view(M, D)
         if dz.dtype != T:
@@ -516,20 +600,46 @@ class StudentEngine:
             del da, dh1
             if i in group_lo:
                 self._bucket_done(group_lo[i], side)
-        # embeddings: h0[b, 0] = cls + pos[0];  h0[b, 1+p] = patches @ Wp^T + bias + pos[1+p]
+        # embeddings: h0[b, 0] = cls + pos[0];  h0[b, tok0+p] = patches @ Wp^T + bias + ppos[p];  h0[b, tok0+P+r] = reg[r] + reg_pos[r]
         emb = vit.embeddings
         gpos, acc = self._grad(emb.position_embeddings)
-        ops.colsum(dh.view(b, NTOK * D), gpos.view(NTOK * D), acc, ws)
-        gcls, acc = self._grad(emb.cls_token)
-        ops.colsum(dh.view(b, NTOK * D)[:, :D], gcls.view(D), acc, ws)
+        tmp = None
+        if geo.key == (GRID, GRID, 1, 0, False):  # plain DeiT at 224: the token sums ARE the position-embedding gradient
+            ops.colsum(dh.view(b, NTOK * D), gpos.view(NTOK * D), acc, ws)
+        else:
+            tmp = torch.empty(NTOK * D, dtype=torch.float32, device=dev)  # sum over the batch, per token
+            ops.colsum(dh.view(b, NTOK * D), tmp, False, ws)
+            gp = gpos.view(GRID * GRID + 1, D)
+            if geo.tok0:
+                ops.unpermute3(tmp[:D], gp[0], 1, 1, D, 0, 0, 1, acc)
+            elif not acc:
+                ops.fill_zero(gp[0])  # nocls-: position row 0 is never used (backbones.py:91)
+            tp = tmp[geo.tok0 * D:(geo.tok0 + P) * D]
+            if not geo.interp:
+                ops.unpermute3(tp, gp[1:], 1, 1, P * D, 0, 0, 1, acc)
+            else:  # through the interpolation matrix: d pos[1:] = W^T @ d ppos   (exact-f32 MFMA path)
+                _w, wt, p4 = self._interp_mats(geo, dev)
+                tpT = torch.zeros(D, p4, dtype=torch.float32, device=dev)
+                ops.cast_transpose(tp.view(P, D), tpT, ldd=p4)
+                ops.linear(wt, tpT, out=gp[1:], resid=gp[1:] if acc else None)
+            if geo.nreg:
+                treg = tmp[(geo.tok0 + P) * D:]
+                g, a2 = self._grad(emb.reg_token)
+                ops.unpermute3(treg, g.view(-1), 1, 1, geo.nreg * D, 0, 0, 1, a2)
+                g, a2 = self._grad(emb.reg_pos_embed)
+                ops.unpermute3(treg, g.view(-1), 1, 1, geo.nreg * D, 0, 0, 1, a2)
+        if geo.tok0:
+            gcls, acc = self._grad(emb.cls_token)
+            ops.colsum(dh.view(b, NTOK * D)[:, :D], gcls.view(D), acc, ws)
         gpb, acc = self._grad(emb.patch_embeddings.projection.bias)
         # bias gradient = sum over images and patch tokens: two column sums (tokens of one image, then images)
-        tmp = torch.empty(NTOK * D, dtype=torch.float32, device=dev)
-        ops.colsum(dh.view(b, NTOK * D), tmp, False, ws)
-        ops.colsum(tmp.view(NTOK, D)[1:], gpb, acc, ws)
+        if tmp is None:
+            tmp = torch.empty(NTOK * D, dtype=torch.float32, device=dev)
+            ops.colsum(dh.view(b, NTOK * D), tmp, False, ws)
+        ops.colsum(tmp.view(NTOK, D)[geo.tok0:geo.tok0 + P], gpb, acc, ws)
         gpw, acc = self._grad(emb.patch_embeddings.projection.weight)
-        rmap = self._plan("patch")
-        Mp = b * GRID * GRID
+        rmap = self._plan("patch", geo)
+        Mp = b * P
         splits = ops.wgrad_splits(Mp, D, 768)
         slabs = ws[: splits * D * 768]
         ops.gemm_wgrad(dh, saved["patches"], slabs, Mp, D, D, 1, splits, rmap)
@@ -566,13 +676,18 @@ class StudentEngine:
     def _translator_fwd(self, z: torch.Tensor, names: List[str], save: bool):
         dev, T, C = z.device, self.dtype, self.D
         oc = self._operands(dev)
-        b = z.shape[0]
+        b, NTOK = z.shape[0], z.shape[1]
+        if NTOK != self.geo224.ntok:
+            raise NotImplementedError(f"the translator heads take the 14x14 patch grid of a 224x224 input ({self.geo224.ntok} tokens), "
+                                      f"got {NTOK} tokens (the reference's heads reshape to 14x14 too, adapter_heads.py:281)")
         z = z.contiguous()
         outs, saved = [], []
         for t in names:
             hm = self._head(t)
             pf = f"h:{t}."
             if hm.kind == "cls":  # Linear on token 0: rows of z with stride NTOK*C (adapter_heads.py:50-57)
+                if not self.tok0:
+                    raise AssertionError("LinearAdapterHead needs a CLS token (adapter_heads.py:53: assert backbone_no_cls == False)")
                 outs.append(ops.linear(z[:, 0, :], oc[pf + "w"], hm.adapter["0"].bias))
                 if save:
                     saved.append(None)
@@ -599,7 +714,7 @@ class StudentEngine:
         z = saved["z"]
         dev, T, C, b = z.device, self.dtype, self.D, saved["b"]
         oc = self._operands(dev)
-        dz = torch.zeros(b, NTOK, C, dtype=T, device=dev)
+        dz = torch.zeros(b, self.geo224.ntok, C, dtype=T, device=dev)  # register-token rows stay zero (stripped before the heads)
         for hi, t in enumerate(names):
             dp = dpreds[hi]
             hm = self._head(t)
@@ -720,8 +835,8 @@ class StudentEngine:
 
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng: StudentEngine, img, channels_last, do_rescale, do_normalize, *params):
-        z, saved = eng._backbone_fwd(img, channels_last, do_rescale, do_normalize, save=True)
+    def forward(ctx, eng: StudentEngine, img, channels_last, do_rescale, do_normalize, geo, *params):
+        z, saved = eng._backbone_fwd(img, channels_last, do_rescale, do_normalize, save=True, geo=geo)
         ctx.eng, ctx.saved, ctx.nparams = eng, saved, len(params)
         return z
 
@@ -729,7 +844,7 @@ class _BackboneFn(torch.autograd.Function):
     def backward(ctx, dz):
         ctx.eng._backbone_bwd(ctx.saved, dz)
         ctx.saved = None
-        return (None,) * (5 + ctx.nparams)
+        return (None,) * (6 + ctx.nparams)
 
 
 class _TranslatorFn(torch.autograd.Function):

@@ -24,8 +24,19 @@ NUM_LAYERS = 12
 PATCH = 16
 IMAGE = 224
 GRID = 14
-NTOK = 197
+NTOK = 197          # tokens of the plain DeiT at 224x224: CLS + 14*14 patches
+MAX_TOKENS = 256    # sequence length the attention kernels hold in LDS
 INIT_RANGE = 0.02  # ViTConfig.initializer_range
+
+
+def backbone_variant(model_name: str):
+    """(base HF name, has CLS token, register tokens) -- dispatch order of the reference's build_backbone (backbones.py:519-526):
+    "reg" is tested before "nocls"."""
+    if "reg" in model_name:
+        return model_name.replace("reg-", ""), True, None  # register count comes from the num_reg_tokens kwarg (default 7)
+    if "nocls" in model_name:
+        return model_name.replace("nocls-", ""), False, 0
+    return model_name, True, 0
 
 
 class _Holder(nn.Module):
@@ -66,10 +77,17 @@ class _PatchEmbeddings(_Holder):
 
 
 class _Embeddings(_Holder):
-    def __init__(self, D: int):
+    """Parameter names / registration order of HF ViTEmbeddings and of the reference's NoCLS / Reg subclasses
+    (backbones.py:26-37: cls_token removed, position_embeddings keeps its 197 rows; :128-150: reg_token and reg_pos_embed)."""
+
+    def __init__(self, D: int, has_cls: bool = True, num_reg_tokens: int = 0):
         super().__init__()
-        self.cls_token = nn.Parameter(torch.empty(1, 1, D))
+        if has_cls:
+            self.cls_token = nn.Parameter(torch.empty(1, 1, D))
         self.position_embeddings = nn.Parameter(torch.empty(1, NTOK, D))
+        if num_reg_tokens > 0:
+            self.reg_token = nn.Parameter(torch.empty(1, num_reg_tokens, D))
+            self.reg_pos_embed = nn.Parameter(torch.empty(1, num_reg_tokens, D))
         self.patch_embeddings = _PatchEmbeddings(D)
 
 
@@ -101,10 +119,11 @@ class _Layer(_Holder):
 class ViTParams(_Holder):
     """Same parameter names as HF ``ViTModel`` (pooler removed: the reference sets it to Identity, backbones.py:283)."""
 
-    def __init__(self, D: int, heads: int, F: int):
+    def __init__(self, D: int, heads: int, F: int, has_cls: bool = True, num_reg_tokens: int = 0):
         super().__init__()
         self.hidden_size, self.num_heads, self.intermediate_size = D, heads, F
-        self.embeddings = _Embeddings(D)
+        self.has_cls, self.num_reg_tokens = has_cls, num_reg_tokens
+        self.embeddings = _Embeddings(D, has_cls, num_reg_tokens)
         self.layers = nn.ModuleList([_Layer(D, F) for _ in range(NUM_LAYERS)])
         self.layernorm = LayerNormParams(D)
         self.reset_parameters()
@@ -140,20 +159,30 @@ DEIT_HUB_PROCESSOR = {"size": 256, "crop_size": 224, "resample": 3,
 
 class DeiT(nn.Module):
     """DeiT student (reference ``DeiT`` backbones.py:255-341).  ``forward`` takes uint8 images and returns the last
-    hidden state [B, 197, D]; image preprocessing (rescale + normalise) is fused into the ingest kernel."""
+    hidden state [B, 197, D]; image preprocessing (rescale + normalise) is fused into the ingest kernel.
+
+    The ``nocls-`` (``DeiTNoCLS``, backbones.py:344-416: no CLS token, 196 tokens) and ``reg-`` (``DeiTReg``, :419-503: 7
+    register tokens appended after the patches, 204 tokens) students are the same container with a different token layout;
+    they carry the reference's marker attributes (``no_cls`` / ``num_reg_tokens``) that ``RobotVisionFM`` keys on."""
 
     def __init__(self, model_name: str = "facebook/deit-small-patch16-224", pretrained: bool = False, image_size: int = 224,
-                 processor: Optional[dict] = None):
+                 processor: Optional[dict] = None, num_reg_tokens: int = 7):
         super().__init__()
-        if model_name not in ARCH:
+        base, has_cls, nreg = backbone_variant(model_name)
+        nreg = int(num_reg_tokens) if nreg is None else nreg
+        if base not in ARCH:
             raise NotImplementedError(f"Requested {model_name} is not implemented.")
         if pretrained:
             raise NotImplementedError("pretrained HF weights cannot be fetched offline; load a checkpoint with "
                                       "RobotVisionFM.load_pretrained_weights instead")
         self.model_name = model_name
         self.image_size = image_size
-        D, heads, F = ARCH[model_name]
-        self.model = ViTParams(D, heads, F)
+        D, heads, F = ARCH[base]
+        self.model = ViTParams(D, heads, F, has_cls, nreg)
+        if not has_cls:
+            self.no_cls = True  # reference marker attribute (RobotVisionFM: hasattr(backbone, "no_cls"))
+        if nreg > 0:
+            self.num_reg_tokens = nreg
         self._engine = None  # set by RobotVisionFM
         # The reference takes its image processor from the hub (AutoProcessor.from_pretrained, backbones.py:292); nothing can
         # be fetched here, so the configuration is explicit (SURVEY.md App. D-1).  Default: resize to 224x224 bilinear, no
@@ -189,17 +218,23 @@ class DeiT(nn.Module):
 
     def forward(self, x: Any, do_resize: bool = True, interpolate_pos_encoding: Optional[bool] = None, do_rescale: bool = True,
                 do_normalize: bool = True) -> torch.Tensor:
+        """-> last hidden state [B, tokens, D].  ``interpolate_pos_encoding=True`` (with ``do_resize=False``) runs the student
+        on images of another size: the 14x14 patch position table is interpolated bicubically to the image's patch grid
+        (HF ViTEmbeddings.interpolate_pos_encoding for DeiT; the reference's own variant for nocls- / reg-)."""
         if self._engine is None:
             raise RuntimeError("DeiT is driven by RobotVisionFM's engine; construct it through RobotVisionFM")
-        if interpolate_pos_encoding:
-            raise NotImplementedError("interpolate_pos_encoding is outside the round-1 hot path (SURVEY.md sec. 8f-3)")
-        return self._engine.backbone(x, do_rescale=do_rescale, do_normalize=do_normalize, do_resize=do_resize)
+        return self._engine.backbone(x, do_rescale=do_rescale, do_normalize=do_normalize, do_resize=do_resize,
+                                     interpolate_pos_encoding=bool(interpolate_pos_encoding))
+
+
+DeiTNoCLS = DeiT  # same container; the model name selects the token layout
+DeiTReg = DeiT
 
 
 def build_backbone(model_name: str, pretrained: bool = False, image_size: int = 224, **kwargs: Any) -> nn.Module:
-    """Reference ``build_backbone`` backbones.py:506-526 (reg-/nocls- variants are "next")."""
-    if "reg" in model_name or "nocls" in model_name:
-        raise NotImplementedError(f"{model_name}: register-token / no-CLS variants are not part of the hot path yet")
-    if "deit" in model_name:
-        return DeiT(model_name=model_name, pretrained=pretrained, image_size=image_size, processor=kwargs.get("processor"))
+    """Reference ``build_backbone`` backbones.py:506-526: "reg" names -> DeiTReg (kwarg num_reg_tokens), "nocls" -> DeiTNoCLS,
+    "deit" -> DeiT."""
+    if "reg" in model_name or "nocls" in model_name or "deit" in model_name:
+        extra = {"num_reg_tokens": kwargs["num_reg_tokens"]} if "num_reg_tokens" in kwargs and "reg" in model_name else {}
+        return DeiT(model_name=model_name, pretrained=pretrained, image_size=image_size, processor=kwargs.get("processor"), **extra)
     raise NotImplementedError(f"Requested {model_name} is not implemented.")

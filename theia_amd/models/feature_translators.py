@@ -34,7 +34,9 @@ class LightConvFeatureTranslator(nn.Module):
     def forward(self, x: torch.Tensor, target_model_names: Optional[list] = None, backbone_no_cls: bool = False) -> dict:
         if self._engine is None:
             raise RuntimeError("the translator is driven by RobotVisionFM's engine")
-        assert not backbone_no_cls, "DeiT backbone always carries a CLS token"
+        # backbone_no_cls (nocls- students: heads take all 196 tokens instead of x[:, 1:], adapter_heads.py:355-356) is a property
+        # of the engine's token layout: it reads the patch rows in place for every student
+        assert bool(backbone_no_cls) == (self._engine.tok0 == 0), "backbone_no_cls does not match the student's token layout"
         names = target_model_names if target_model_names is not None else self.target_model_names
         return self._engine.translator(x, list(names))
 

@@ -127,8 +127,9 @@ class RobotVisionFM(nn.Module):
 
     def forward(self, x: Any, target_model_names: Optional[list] = None, **kwargs: Any) -> dict:
         x = self.backbone(x, **kwargs)
-        if self.num_reg_tokens > 0:  # pragma: no cover - DeiT has none
-            x = x[:, :-self.num_reg_tokens]
+        # reference: `x = x[:, :-num_reg_tokens]` here (rvfm.py:133-134).  The engine's heads read the 196 patch rows of the
+        # full token matrix in place (row-map offset/stride), so the register tokens are skipped without a copy and their
+        # rows of the gradient stay zero -- same values, no slice.
         return self.translator(x, target_model_names, backbone_no_cls=self.no_cls)
 
     # ---------------------------------------------------------------- losses (rvfm.py:138-185)

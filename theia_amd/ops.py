@@ -371,14 +371,22 @@ def resize_u8(img: torch.Tensor, channels_last: bool, out_h: int, out_w: int, re
 
 
 def patchify(img: torch.Tensor, lut: torch.Tensor, out: torch.Tensor, channels_last: bool) -> None:
+    """uint8 [b,H,W,3] / [b,3,H,W] -> [b*(H/16)*(W/16), 768] patch matrix through the preprocessing LUT"""
     b = img.shape[0]
-    N.check(N.lib().theia_patchify_u8(img.data_ptr(), lut.data_ptr(), out.data_ptr(), b, int(channels_last), _dt(out),
-                                      N.stream_ptr()), "theia_patchify_u8")
+    H, W = (img.shape[1], img.shape[2]) if channels_last else (img.shape[2], img.shape[3])
+    N.check(N.lib().theia_patchify_u8_hw(img.data_ptr(), lut.data_ptr(), out.data_ptr(), b, H, W, int(channels_last), _dt(out),
+                                         N.stream_ptr()), "theia_patchify_u8")
 
 
 def write_cls(cls: torch.Tensor, pos: torch.Tensor, h: torch.Tensor, b: int, ntok: int, D: int) -> None:
     N.check(N.lib().theia_write_cls(cls.data_ptr(), pos.data_ptr(), h.data_ptr(), b, ntok, D, _dt(h), N.stream_ptr()),
             "theia_write_cls")
+
+
+def write_tokens(tok: torch.Tensor, pos: torch.Tensor, h: torch.Tensor, b: int, ntok: int, t0: int, cnt: int, D: int) -> None:
+    """h[b, t0 + r, :] = tok[r] + pos[r] (f32 [cnt, D] each)"""
+    N.check(N.lib().theia_write_tokens(tok.data_ptr(), pos.data_ptr(), h.data_ptr(), b, ntok, t0, cnt, D, _dt(h), N.stream_ptr()),
+            "theia_write_tokens")
 
 
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
