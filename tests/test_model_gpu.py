@@ -281,7 +281,7 @@ def test_non_224_inputs_go_through_the_processor_resize(golden_dir):
         z0 = m.forward_feature(torch.from_numpy(a[None]))
         z1 = m.forward_feature(torch.from_numpy(g["down_chw_img"]))
     assert torch.equal(zl[0], z0[0]) and torch.equal(zl[1], z1[0])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="doesn't match model"):  # HF ViTEmbeddings raises ValueError for a size mismatch too
         m.forward_feature(torch.from_numpy(a[None]), do_resize=False)
 
 
