@@ -108,6 +108,12 @@ typedef struct theia_gemm_args {
      * cross-checks the automatic choice against a forced one). */
     int32_t tile;
     int32_t reserved;
+    /* optional: f32 [images][2], accumulated ATOMICALLY with (sum, sum of squares) of the stored output values of each image
+     * (image = GEMM row / (rows_h*rows_w), needs rows_h*rows_w >= 128).  The whole-sample LayerNorm that follows a translator
+     * convolution (adapter_heads.py:306-324) takes its statistics from here instead of re-reading the activation; the caller
+     * zeroes the buffer before the first launch that writes the tensor (the 4 output-parity launches of a stride-2 transposed
+     * convolution add into the same sums). */
+    float* ln_sums;
 } theia_gemm_args_t;
 
 int theia_gemm_nt(const theia_gemm_args_t* args, int dtype, void* stream);
@@ -141,7 +147,7 @@ typedef struct theia_wgrad_args {
     float* bias_slabs;
     float* bias_out;
     int32_t bias_accumulate;
-    int32_t reserved;
+    int32_t defer_bias_reduce; /* 1: only write bias_slabs; the caller reduces them with theia_wgrad_finish (same launch as the weights) */
 } theia_wgrad_args_t;
 
 int theia_gemm_wgrad(const theia_wgrad_args_t* args, int dtype, void* stream);
@@ -152,6 +158,12 @@ int theia_wgrad_splits(int M, int N, int Ktot);
 /* out[n*sn + slot*ss + ci*sc] (+)= sum_s slab[s][n][slot*C + ci]   (f32; permutes into the PyTorch layout) */
 int theia_wgrad_reduce(const float* slabs, int splits, int N, int kslots, int C, float* out, int64_t sn,
                        int64_t ss, int64_t sc, int accumulate, void* stream);
+
+/* The same reduction with BOTH sides coalesced (the permutation goes through an LDS tile) and, optionally, the bias partials of
+ * the same weight-gradient GEMM (theia_wgrad_args_t.defer_bias_reduce = 1) reduced by the same launch:
+ * bias_out[n] (+)= sum_s bias_slabs[s*N + n].  kslots <= 16. */
+int theia_wgrad_finish(const float* slabs, int splits, int N, int kslots, int C, float* out, int64_t sn, int64_t ss, int64_t sc,
+                       int accumulate, const float* bias_slabs, float* bias_out, int bias_accumulate, void* stream);
 
 /* out[n] (+)= sum_m x[m*ld + n]   (bias gradients; x has `dtype` elements, out f32)  */
 int theia_colsum(const void* x, int64_t M, int N, int64_t ld, float* out, float* workspace, int accumulate,
@@ -192,6 +204,9 @@ int theia_cast_batch(const theia_cast_job_t* jobs_device, int njobs, int64_t tot
 /* f32 -> f32 version writing with destination strides: dst[i*t0 + j*t1 + k*t2] (+)= src[(i*d1+j)*d2+k] */
 int theia_unpermute3_f32(const float* src, float* dst, int d0, int d1, int d2, int64_t t0, int64_t t1,
                          int64_t t2, int accumulate, void* stream);
+
+/* dst[c*R + r] (+)= src[r*C + c]  (f32 transpose, both sides coalesced: LayerNorm[C,H,W] affine gradients [HW][C] -> [C][HW]) */
+int theia_transpose_acc_f32(const float* src, float* dst, int R, int C, int accumulate, void* stream);
 
 /* Image resize of the reference's HF image processor (models/backbones.py:337-339 -> Pillow Image.resize, two-pass 8-bit
  * resampling, Pillow 12.2.0 src/libImaging/Resample.c): src uint8 [b, in_h, in_w, 3] (channels_last) or [b, 3, in_h, in_w]
@@ -239,6 +254,10 @@ size_t theia_layernorm_bwd_workspace_bytes(int64_t M, int D);
  * ---------------------------------------------------------------------------------------------- */
 int theia_layernorm_chw_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
                             float* workspace, int b, int64_t E, float eps, int dtype, void* stream);
+/* the same with the per-sample (sum, sum of squares) already known (theia_gemm_args_t.ln_sums of the producing GEMM): one pass,
+ * 4 B/element in bf16 instead of 6; writes stats (mean, rstd) for the backward pass */
+int theia_layernorm_chw_fwd_sums(const void* x, const float* gamma, const float* beta, void* y, const float* sums, float* stats,
+                                 int b, int64_t E, float eps, int dtype, void* stream);
 /* dx = LNbwd(dy) * (relu_mask ? (x > 0) : 1): the optional mask folds the backward of the ReLU that produced x.
  * dgamma/dbeta f32 [E] (+)= sum over the batch of dy*xhat / dy. */
 int theia_layernorm_chw_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,

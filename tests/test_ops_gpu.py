@@ -595,3 +595,67 @@ def test_adamw_matches_torch():
         opt.step()
         ops.adamw_step(p, g.to(dev), m, v, 1e-2, 0.9, 0.999, 1e-8, 0.01, step)
     assert relerr(p, ref_p.detach()) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["conv_p1", "convT_s1", "convT_s2_p1", "convT_s2_op1"])
+@pytest.mark.parametrize("tile", [0, 128128, 256256])
+def test_conv_epilogue_emits_layernorm_statistics(dt, kind, tile):
+    """theia_gemm_args_t.ln_sums: per-image (sum, sum of squares) of the STORED convolution output, accumulated by the GEMM
+    epilogue (all four output-parity launches of a stride-2 transposed convolution add into the same sums; images of 225 / 240
+    rows straddle the 128-row wave tiles), and the one-pass LayerNorm[C,H,W] that consumes them == the three-pass one."""
+    from theia_amd import ops, _native as Nn
+    dev = _dev()
+    b, C = 5, 64
+    IH = {"conv_p1": 16, "convT_s1": 14, "convT_s2_p1": 16, "convT_s2_op1": 31}[kind]
+    x = h((b, IH, IH, C), 21, 1.0)
+    W = h((C, C, 3, 3), 22, 1.0 / math.sqrt(9 * C))
+    bias = h((C,), 23, 0.1)
+    if kind == "conv_p1":
+        plan = ops.plan_conv3x3(C, IH)
+    else:
+        s, p, op = {"convT_s1": (1, 0, 0), "convT_s2_p1": (2, 1, 0), "convT_s2_op1": (2, 0, 1)}[kind]
+        plan = ops.plan_convT3x3(C, IH, s, p, op)
+    OH = plan.out_hw
+    xd, wf = x.to(dev, dt), _pack(plan.pack_fwd, W, dt, dev)
+    out = torch.zeros(b, OH, OH, C, dtype=dt, device=dev)
+    sums = torch.zeros(b, 2, dtype=torch.float32, device=dev)
+    for rmap, mpi in plan.fwd:
+        ops.gemm_nt(xd, wf, out, b * mpi, C, rmap.ntaps * C, rmap, 9 * C, C, bias=bias.to(dev), act=Nn.ACT_RELU, tile=tile, ln_sums=sums)
+    o64 = out.double().view(b, -1)
+    assert relerr(sums[:, 0], o64.sum(1)) < 1e-5 and relerr(sums[:, 1], (o64 * o64).sum(1)) < 1e-5
+    E = OH * OH * C
+    g = (h((E,), 52, 0.2) + 1.0).to(dev)
+    s_ = h((E,), 53, 0.2).to(dev)
+    y3, st3 = ops.layernorm_chw_fwd(out.view(b, E), g, s_, 1e-5)
+    y1, st1 = ops.layernorm_chw_fwd(out.view(b, E), g, s_, 1e-5, sums=sums)
+    assert relerr(st1, st3) < 1e-5
+    assert relerr(y1.float(), y3.float()) < (1e-5 if dt == torch.float32 else 8e-3)  # bf16: one output ulp where rstd differs in its last bits
+
+
+def test_transpose_acc_and_wgrad_finish_layouts():
+    """theia_transpose_acc_f32 and theia_wgrad_finish against torch indexing: every weight layout of the hot path (nn.Linear
+    [n][c], Conv2d [co][ci][3][3], ConvTranspose2d [ci][co][3][3] in both reduction orders), ragged tile edges, accumulation,
+    and the bias partials reduced by the same launch."""
+    from theia_amd import ops
+    dev = _dev()
+    src = h((300, 72), 1).to(dev)
+    dst = torch.full((72, 300), 0.5, device=dev)
+    ops.transpose_acc(src, dst, 300, 72, True)
+    assert torch.equal(dst, src.t() + 0.5)
+    ops.transpose_acc(src, dst, 300, 72, False)
+    assert torch.equal(dst, src.t().contiguous())
+    splits, Nn_, C = 3, 40, 72
+    for kslots, (sn, ss, sc), view in ((1, (C, 0, 1), lambda t: t.view(Nn_, C)),
+                                       (9, (C * 9, 1, 9), lambda t: t.view(Nn_, C, 9).permute(0, 2, 1)),      # W[n][c][slot]
+                                       (9, (9, 1, Nn_ * 9), lambda t: t.view(C, Nn_, 9).permute(1, 2, 0))):   # W[c][n][slot]
+        slabs = h((splits, Nn_, kslots, C), 7 + kslots).to(dev)
+        want = slabs.sum(0)  # [n][slot][c]
+        bpart = h((splits, Nn_), 9).to(dev)
+        for acc in (False, True):
+            out = torch.full((Nn_ * kslots * C,), 0.25, device=dev)
+            bout = torch.full((Nn_,), 0.25, device=dev)
+            ops.wgrad_finish(slabs, splits, Nn_, kslots, C, out, sn, ss, sc, acc, (bpart, bout, acc))
+            got = view(out).reshape(Nn_, kslots, C)
+            assert relerr(got, want + (0.25 if acc else 0.0)) < 1e-6
+            assert relerr(bout, bpart.sum(0) + (0.25 if acc else 0.0)) < 1e-6

@@ -46,6 +46,7 @@ class GemmArgs(C.Structure):
         ("ldw", C.c_int32), ("ldo", C.c_int32), ("act", C.c_int32),
         ("map", RowMap),
         ("tile", C.c_int32), ("reserved", C.c_int32),
+        ("ln_sums", C.c_void_p),
     ]
 
 
@@ -64,7 +65,7 @@ class WgradArgs(C.Structure):
         ("dy", C.c_void_p), ("a", C.c_void_p), ("slabs", C.c_void_p),
         ("M", C.c_int32), ("N", C.c_int32), ("ldo", C.c_int32), ("kslots", C.c_int32), ("splits", C.c_int32),
         ("map", RowMap),
-        ("bias_slabs", C.c_void_p), ("bias_out", C.c_void_p), ("bias_accumulate", C.c_int32), ("reserved", C.c_int32),
+        ("bias_slabs", C.c_void_p), ("bias_out", C.c_void_p), ("bias_accumulate", C.c_int32), ("defer_bias_reduce", C.c_int32),
     ]
 
 
@@ -81,6 +82,8 @@ _SIGNATURES = {
     "theia_wgrad_splits": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "theia_wgrad_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
                                      C.c_int64, C.c_int, C.c_void_p]),
+    "theia_wgrad_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "theia_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "theia_colsum_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "theia_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
@@ -91,6 +94,7 @@ _SIGNATURES = {
                                       C.c_int, C.c_void_p]),
     "theia_unpermute3_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64,
                                        C.c_int, C.c_void_p]),
+    "theia_transpose_acc_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "theia_patchify_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "theia_patchify_u8_hw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "theia_write_cls": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -99,6 +103,7 @@ _SIGNATURES = {
     "theia_layernorm_bwd": (C.c_int, [C.c_void_p] * 10 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "theia_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "theia_layernorm_chw_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
+    "theia_layernorm_chw_fwd_sums": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "theia_layernorm_chw_bwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "theia_layernorm_chw_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
     "theia_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

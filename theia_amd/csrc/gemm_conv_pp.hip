@@ -32,7 +32,7 @@ struct conv_taps_t {
 
 __device__ __forceinline__ int cv_f(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
-template <typename T>
+template <typename T, bool SUMS = false>
 __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args_t p, const conv_taps_t tp) {
     constexpr int BM = 256, BN = 256, WAVES_N = 4;
     constexpr int NB = 6, PD = NB - 1;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
     asm volatile("" ::: "memory");
 
     float* ep = reinterpret_cast<float*>(smem) + wave * (64 * (WN + 4));
-    gt_epilogue<T, WM, WN>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
+    gt_epilogue<T, WM, WN, SUMS>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
 // Does the row map describe a convolution this kernel takes?  (one 16x16 output image per 256-row tile, stride 1, taps a
@@ -255,10 +255,15 @@ int theia_gemm_conv_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_pp_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_pp_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_pp_kernel<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_pp_kernel<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int tiles = (a->M / 256) * cdiv_i(a->N, 256);
-    if (dtype == THEIA_BF16) hipLaunchKernelGGL(gemm_conv_pp_kernel<bf16_t>, dim3(tiles), dim3(512), lds, stream, *a, tp);
+    const bool sums = a->ln_sums != nullptr;
+    if (dtype == THEIA_BF16 && sums) hipLaunchKernelGGL((gemm_conv_pp_kernel<bf16_t, true>), dim3(tiles), dim3(512), lds, stream, *a, tp);
+    else if (dtype == THEIA_BF16) hipLaunchKernelGGL(gemm_conv_pp_kernel<bf16_t>, dim3(tiles), dim3(512), lds, stream, *a, tp);
+    else if (sums) hipLaunchKernelGGL((gemm_conv_pp_kernel<float, true>), dim3(tiles), dim3(512), lds, stream, *a, tp);
     else hipLaunchKernelGGL(gemm_conv_pp_kernel<float>, dim3(tiles), dim3(512), lds, stream, *a, tp);
     THEIA_CHECK_LAUNCH("theia_gemm_nt(conv)");
     return THEIA_OK;

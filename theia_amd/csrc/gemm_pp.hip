@@ -53,7 +53,7 @@ __device__ __forceinline__ int pp_f(int row) { return (4 - ((row >> 2) & 3)) & 3
 
 // CXXR: A/B switch (THEIA_PP_READS=cxx) -- fragment reads as plain C++ LDS loads, the form in which hipcc puts `s_waitcnt vmcnt(0)`
 // in front of them (every LDS-DMA in flight is drained at the top of each iteration)
-template <typename T, bool CXXR = false>
+template <typename T, bool CXXR = false, bool SUMS = false>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t p) {
     constexpr int BM = 256, BN = 256, WAVES_N = 4;
     constexpr int NSTAGE = 4;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
 
     PP_PHASE(4)
     float* ep = reinterpret_cast<float*>(smem) + wave * (64 * (WN + 4));
-    gt_epilogue<T, WM, WN>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
+    gt_epilogue<T, WM, WN, SUMS>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
     PP_PHASE(5)
 #ifdef PP_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -298,7 +298,16 @@ int theia_gemm_nt_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t s
         cxx_reads = (e != nullptr && strcmp(e, "cxx") == 0) ? 1 : 0;
         if (cxx_reads) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
-    if (dtype == THEIA_BF16 && cxx_reads) hipLaunchKernelGGL((gemm_nt_pp_kernel<bf16_t, true>), dim3(tiles), dim3(512), lds, stream, *a);
+    if (a->ln_sums != nullptr) {
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<bf16_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<float, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr2 = true;
+        }
+        if (dtype == THEIA_BF16) hipLaunchKernelGGL((gemm_nt_pp_kernel<bf16_t, false, true>), dim3(tiles), dim3(512), lds, stream, *a);
+        else hipLaunchKernelGGL((gemm_nt_pp_kernel<float, false, true>), dim3(tiles), dim3(512), lds, stream, *a);
+    } else if (dtype == THEIA_BF16 && cxx_reads) hipLaunchKernelGGL((gemm_nt_pp_kernel<bf16_t, true>), dim3(tiles), dim3(512), lds, stream, *a);
     else if (dtype == THEIA_BF16) hipLaunchKernelGGL(gemm_nt_pp_kernel<bf16_t>, dim3(tiles), dim3(512), lds, stream, *a);
     else hipLaunchKernelGGL(gemm_nt_pp_kernel<float>, dim3(tiles), dim3(512), lds, stream, *a);
     THEIA_CHECK_LAUNCH("theia_gemm_nt(pp)");

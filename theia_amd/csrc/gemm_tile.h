@@ -104,7 +104,9 @@ template <typename T> __device__ __forceinline__ float gt_gelu_grad(float x) {
 // The row passes are a ROLLED loop over groups of passes: fully unrolled the epilogue was ~70 KB of straight-line code
 // executed once per workgroup -- more than the 64 KB instruction cache, and the instruction fetch (not the stores) set its
 // duration (29-36k cycles per 256x256 tile; tools/pp_trace.hip).
-template <typename T, int WM, int WN, int GPMAX = 4>
+// SUMS: also accumulate p.ln_sums (a separate instantiation, launched only for the GEMMs that feed a whole-sample LayerNorm, so
+// that every other launch pays nothing for it)
+template <typename T, int WM, int WN, bool SUMS = false, int GPMAX = 4>
 __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], float* ep /* wave-private LDS */,
                                             const theia_gemm_args_t& p, int m_wave0, int n_wave0, int lane) {
     constexpr int FM = WM / 16, FN = WN / 16;
@@ -160,6 +162,13 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
     bool nlive[GP];
     int64_t noff[GP];
     gt_u32x4 npre[GP];
+    // optional per-image (sum, sum of squares) of the stored values (theia_gemm_args_t.ln_sums): a wave tile of WM <= 128 rows
+    // touches at most two images (rows per image >= 128, checked by the dispatch): slot 0 = the image of the tile's first row
+    float* const lsum = SUMS ? p.ln_sums : nullptr;
+    int img0, dummy_rem;
+    img0 = gt_divmod(m_wave0 < p.M ? m_wave0 : 0, R, rcp_R, dummy_rem);
+    const int m_split = (img0 + 1) * R;  // first GEMM row of the second image
+    float ls0 = 0.f, lq0 = 0.f, ls1 = 0.f, lq1 = 0.f;
     // The prefetch loads are inline asm, invisible to the compiler's waitcnt bookkeeping: it would otherwise wait with
     // vmcnt(0) at their first use, i.e. also for every store issued since.  The explicit counted waits below (tied to the
     // registers by "+v") are the only synchronisation of npre[].  Every pass issues its output store unconditionally
@@ -254,9 +263,39 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
             if (v[0] == 123456.f)
 #endif
             store8(live[q] ? O + o : dump, v);
+            if constexpr (SUMS) {
+                float s = 0.f, sq = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float r = sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(v[j])) : v[j];  // the value as stored
+                    s += r;
+                    sq += r * r;
+                }
+                s = live[q] ? s : 0.f;
+                sq = live[q] ? sq : 0.f;
+                const bool first = m_wave0 + lrow + (g * GP + q) * RPP < m_split;
+                ls0 += first ? s : 0.f;
+                lq0 += first ? sq : 0.f;
+                ls1 += first ? 0.f : s;
+                lq1 += first ? 0.f : sq;
+            }
         }
         // group g+1's rows have landed once at most the GP (or more) stores issued after them are outstanding
         if constexpr (GP == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(npre[0]), "+v"(npre[1]), "+v"(npre[2]), "+v"(npre[3])::"memory");
         else asm volatile("s_waitcnt vmcnt(2)" : "+v"(npre[0]), "+v"(npre[1])::"memory");
+    }
+    if constexpr (SUMS) {
+        ls0 = wave_sum(ls0);
+        lq0 = wave_sum(lq0);
+        ls1 = wave_sum(ls1);
+        lq1 = wave_sum(lq1);
+        if (lane == 0 && m_wave0 < p.M) {
+            atomicAdd(lsum + 2 * img0, ls0);
+            atomicAdd(lsum + 2 * img0 + 1, lq0);
+            if ((int64_t)(img0 + 1) * R < p.M) {  // a second image exists (its sums are zero when the tile did not reach it)
+                atomicAdd(lsum + 2 * (img0 + 1), ls1);
+                atomicAdd(lsum + 2 * (img0 + 1) + 1, lq1);
+            }
+        }
     }
 }

@@ -221,7 +221,7 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
     const int tiles = cdiv_i(a->N, 256) * a->map.ntaps * (a->map.in_c / 256);
     hipLaunchKernelGGL(gemm_wgrad_pp_kernel, dim3(tiles * a->splits), dim3(512), lds, stream, *a);
     THEIA_CHECK_LAUNCH("theia_gemm_wgrad(pp)");
-    if (a->bias_out != nullptr) {
+    if (a->bias_out != nullptr && a->defer_bias_reduce == 0) {
         hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv_i(a->N, 256)), dim3(256), 0, stream, a->bias_slabs, a->splits, a->N,
                            a->bias_out, a->bias_accumulate);
         THEIA_CHECK_LAUNCH("theia_gemm_wgrad(pp bias)");

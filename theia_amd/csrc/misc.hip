@@ -212,6 +212,37 @@ extern "C" int theia_unpermute3_f32(const float* src, float* dst, int d0, int d1
     return THEIA_OK;
 }
 
+// dst[c*R + r] (+)= src[r*C + c]: f32 matrix transpose through a 32x33 LDS tile (both sides coalesced).  The LayerNorm[C,H,W]
+// affine gradients are reduced in the NHWC order of the activations ([HW][C]) and live in the reference's [C][HW] order.
+__global__ __launch_bounds__(256) void transpose_acc_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C,
+                                                            int accumulate) {
+    __shared__ float t[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 8 * j, c = c0 + tx;
+        if (r < R && c < C) t[ty + 8 * j][tx] = src[(int64_t)r * C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + 8 * j, r = r0 + tx;
+        if (r < R && c < C) {
+            const int64_t o = (int64_t)c * R + r;
+            const float v = t[tx][ty + 8 * j];
+            dst[o] = accumulate ? dst[o] + v : v;
+        }
+    }
+}
+extern "C" int theia_transpose_acc_f32(const float* src, float* dst, int R, int C, int accumulate, void* stream) {
+    THEIA_CHECK_ARG(src && dst && R > 0 && C > 0, "theia_transpose_acc_f32: bad args");
+    hipLaunchKernelGGL(transpose_acc_kernel, dim3(cdiv_i(C, 32), cdiv_i(R, 32)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, R,
+                       C, accumulate);
+    THEIA_CHECK_LAUNCH("theia_transpose_acc_f32");
+    return THEIA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Image resize of the HF processor: Pillow's two-pass 8-bit resampling, integer arithmetic only.
 // The double-precision filter weights are computed on the host (theia_amd/preprocess.py) and arrive as 22-bit fixed-point

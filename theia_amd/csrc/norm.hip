@@ -312,12 +312,29 @@ __global__ void chw_finalize_kernel(const float* __restrict__ part, float* __res
     }
 }
 
-template <typename T>
+// SUMS: `stats` holds the per-sample (sum, sum of squares) produced by the convolution's epilogue; mean / rstd are derived here
+// (and written to stats_out for the backward pass) instead of by two more passes over x.
+template <typename T, bool SUMS = false>
 __global__ __launch_bounds__(256) void chw_apply_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ stats,
-                                                        T* __restrict__ y, int64_t E) {
+                                                        T* __restrict__ y, int64_t E, float* __restrict__ stats_out = nullptr,
+                                                        float eps = 0.f) {
     const int sample = blockIdx.y;
-    const float mu = stats[2 * sample], rs = stats[2 * sample + 1];
+    float mu, rs;
+    if constexpr (SUMS) {
+        const double m = (double)stats[2 * sample] / (double)E;
+        double var = (double)stats[2 * sample + 1] / (double)E - m * m;
+        if (var < 0.0) var = 0.0;
+        mu = (float)m;
+        rs = (float)(1.0 / sqrt(var + (double)eps));
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            stats_out[2 * sample] = mu;
+            stats_out[2 * sample + 1] = rs;
+        }
+    } else {
+        mu = stats[2 * sample];
+        rs = stats[2 * sample + 1];
+    }
     const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (e >= E) return;
     float xv[8], g8[8], b8[8], o[8];
@@ -345,10 +362,25 @@ extern "C" int theia_layernorm_chw_fwd(const void* x, const float* gamma, const 
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_fwd(finalize)");
     const dim3 grid((unsigned)((E / 8 + 255) / 256), b);
     if (dtype == THEIA_BF16)
-        hipLaunchKernelGGL(chw_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, stats, (bf16_t*)y, E);
+        hipLaunchKernelGGL((chw_apply_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (const float*)stats, (bf16_t*)y, E, (float*)nullptr, 0.f);
     else
-        hipLaunchKernelGGL(chw_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, gamma, beta, stats, (float*)y, E);
+        hipLaunchKernelGGL((chw_apply_kernel<float, false>), grid, dim3(256), 0, s, (const float*)x, gamma, beta, (const float*)stats, (float*)y, E, (float*)nullptr, 0.f);
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_fwd(apply)");
+    return THEIA_OK;
+}
+
+extern "C" int theia_layernorm_chw_fwd_sums(const void* x, const float* gamma, const float* beta, void* y, const float* sums,
+                                            float* stats, int b, int64_t E, float eps, int dtype, void* stream) {
+    THEIA_CHECK_ARG(x && gamma && beta && y && sums && stats, "theia_layernorm_chw_fwd_sums: null pointer");
+    THEIA_CHECK_ARG(b > 0 && E > 0 && E % 8 == 0, "theia_layernorm_chw_fwd_sums: E=%lld must be a positive multiple of 8", (long long)E);
+    THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16, "theia_layernorm_chw_fwd_sums: bad dtype");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((E / 8 + 255) / 256), b);
+    if (dtype == THEIA_BF16)
+        hipLaunchKernelGGL((chw_apply_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, sums, (bf16_t*)y, E, stats, eps);
+    else
+        hipLaunchKernelGGL((chw_apply_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, gamma, beta, sums, (float*)y, E, stats, eps);
+    THEIA_CHECK_LAUNCH("theia_layernorm_chw_fwd_sums");
     return THEIA_OK;
 }
 

@@ -643,7 +643,7 @@ class StudentEngine:
         splits = ops.wgrad_splits(Mp, D, 768)
         slabs = ws[: splits * D * 768]
         ops.gemm_wgrad(dh, saved["patches"], slabs, Mp, D, D, 1, splits, rmap)
-        ops.wgrad_reduce(slabs, splits, D, 1, 768, gpw, 768, 0, 1, acc)
+        ops.wgrad_finish(slabs, splits, D, 1, 768, gpw, 768, 0, 1, acc)
         self._bucket_done(vit_buckets[3], side)
 
     # ================================================================== translator heads
@@ -667,10 +667,13 @@ class StudentEngine:
         tr = self.rvfm.translator
         return tr.translator_heads[tr.legit_target_model_name_map[t]]
 
-    def _conv_fwd(self, x, wf, bias, plan, b, out, relu: bool):
+    def _conv_fwd(self, x, wf, bias, plan, b, out, relu: bool, sums: Optional[torch.Tensor] = None):
+        """sums: zeroed f32 [b, 2]; every launch (4 output-parity classes for a stride-2 transposed convolution) adds the per-sample
+        (sum, sum of squares) of what it stores: the statistics of the whole-sample LayerNorm that follows."""
         C = self.D
         for rmap, mpi in plan.fwd:
-            ops.gemm_nt(x, wf, out, b * mpi, C, rmap.ntaps * C, rmap, 9 * C, C, bias=bias, act=N.ACT_RELU if relu else N.ACT_NONE)
+            ops.gemm_nt(x, wf, out, b * mpi, C, rmap.ntaps * C, rmap, 9 * C, C, bias=bias, act=N.ACT_RELU if relu else N.ACT_NONE,
+                        ln_sums=sums)
         return out
 
     def _translator_fwd(self, z: torch.Tensor, names: List[str], save: bool):
@@ -694,16 +697,17 @@ class StudentEngine:
                 continue
             s0, s1, s2 = hm.sizes
             chw_ws = self.ws(N.lib().theia_layernorm_chw_workspace_bytes(b, s2 * s2 * C) // 4, dev)
+            sums = torch.zeros(3, b, 2, dtype=torch.float32, device=dev)  # LayerNorm statistics out of the convolutions' epilogues
             u1 = torch.empty(b, 256 * C, dtype=T, device=dev)
-            self._conv_fwd(z, oc[pf + "pad.wf"], hm.pad["1"].bias, self._plan("pad"), b, u1, relu=False)
-            v1, st0 = ops.layernorm_chw_fwd(u1, oc[pf + "ln0.g"], oc[pf + "ln0.b"], LN_EPS_HEAD, chw_ws)
+            self._conv_fwd(z, oc[pf + "pad.wf"], hm.pad["1"].bias, self._plan("pad"), b, u1, relu=False, sums=sums[0])
+            v1, st0 = ops.layernorm_chw_fwd(u1, oc[pf + "ln0.g"], oc[pf + "ln0.b"], LN_EPS_HEAD, chw_ws, sums=sums[0])
             p1, p4 = ("up31", "up64") if hm.kind == "up64" else ("conv16", "conv16")
             u2 = torch.empty(b, s1 * s1 * C, dtype=T, device=dev)
-            self._conv_fwd(v1, oc[pf + "c1.wf"], hm.adapter["1"].bias, self._plan(p1), b, u2, relu=True)
-            v2, st3 = ops.layernorm_chw_fwd(u2, oc[pf + "ln3.g"], oc[pf + "ln3.b"], LN_EPS_HEAD, chw_ws)
+            self._conv_fwd(v1, oc[pf + "c1.wf"], hm.adapter["1"].bias, self._plan(p1), b, u2, relu=True, sums=sums[1])
+            v2, st3 = ops.layernorm_chw_fwd(u2, oc[pf + "ln3.g"], oc[pf + "ln3.b"], LN_EPS_HEAD, chw_ws, sums=sums[1])
             u3 = torch.empty(b, s2 * s2 * C, dtype=T, device=dev)
-            self._conv_fwd(v2, oc[pf + "c4.wf"], hm.adapter["4"].bias, self._plan(p4), b, u3, relu=True)
-            v3, st6 = ops.layernorm_chw_fwd(u3, oc[pf + "ln6.g"], oc[pf + "ln6.b"], LN_EPS_HEAD, chw_ws)
+            self._conv_fwd(v2, oc[pf + "c4.wf"], hm.adapter["4"].bias, self._plan(p4), b, u3, relu=True, sums=sums[2])
+            v3, st6 = ops.layernorm_chw_fwd(u3, oc[pf + "ln6.g"], oc[pf + "ln6.b"], LN_EPS_HEAD, chw_ws, sums=sums[2])
             pred = ops.linear(v3.view(b * s2 * s2, C), oc[pf + "w8"], hm.adapter["8"].bias)
             outs.append(pred.view(b, s2 * s2, -1))
             if save:
@@ -784,9 +788,9 @@ class StudentEngine:
                 dx = ops.layernorm_chw_bwd(dy, x, oc[pf + f"ln{idx}.g"], stats, tmp_g, tmp_b, relu_mask, False, ws[:chw_need])
                 if train:
                     g, acc = self._grad(hm.adapter[idx].weight)
-                    ops.unpermute3(tmp_g, g, hw * hw, 1, C, 1, 0, hw * hw, acc)
+                    ops.transpose_acc(tmp_g, g, hw * hw, C, acc)  # [HW][C] (NHWC reduction order) -> [C][H][W]
                     g, acc = self._grad(hm.adapter[idx].bias)
-                    ops.unpermute3(tmp_b, g, hw * hw, 1, C, 1, 0, hw * hw, acc)
+                    ops.transpose_acc(tmp_b, g, hw * hw, C, acc)
                 return dx
 
             def conv_dgrad(dy, wd, plan, out, resid=None):

@@ -132,7 +132,8 @@ KERNEL_NAMES = {128128: "128x128", 128064: "128x64", 256000: "256x256-2stage", 2
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int, K: int, rmap: RowMap, ldw: int, ldo: int,
             bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, act: int = N.ACT_NONE,
             aux_in: Optional[torch.Tensor] = None, aux_out: Optional[torch.Tensor] = None,
-            rowtab: Optional[torch.Tensor] = None, rowtab_period: int = 0, tile: int = 0, plan_only: bool = False):
+            rowtab: Optional[torch.Tensor] = None, rowtab_period: int = 0, tile: int = 0, plan_only: bool = False,
+            ln_sums: Optional[torch.Tensor] = None):
     """tile: kernel request (0 = the library's choice; see theia_gemm_args_t.tile).  plan_only: launch nothing, return the code
     of the kernel the library would run (theia_gemm_nt_plan)."""
     g = GemmArgs()
@@ -141,6 +142,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int
     g.rowtab, g.rowtab_period = N.ptr(rowtab), rowtab_period
     g.M, g.N, g.K, g.ldw, g.ldo, g.act = M, Nn, K, ldw, ldo, act
     g.map = rmap
+    g.ln_sums = N.ptr(ln_sums)  # f32 [images, 2], zeroed by the caller: += (sum, sum of squares) of each image's stored outputs
     if tile == 0 and GEMM_TILE_HINT != 0:
         if GEMM_TILE_HINT == 128128:
             tile = 128128 if N.lib().theia_gemm_nt_tile(M, Nn, _dt(a)) != 128064 else 0
@@ -188,7 +190,7 @@ def _wgrad_args(dy: torch.Tensor, a: torch.Tensor, slabs: torch.Tensor, M: int, 
 
 def gemm_wgrad(dy: torch.Tensor, a: torch.Tensor, slabs: torch.Tensor, M: int, Nn: int, ldo: int, kslots: int, splits: int,
                rmap: RowMap, bias_out: Optional[torch.Tensor] = None, bias_accumulate: bool = False,
-               bias_slabs: Optional[torch.Tensor] = None) -> bool:
+               bias_slabs: Optional[torch.Tensor] = None, defer_bias: bool = False) -> bool:
     """slab[s][n][slot*in_c + c] = sum_{m in split s} dy[m, n] * a[m, (tap, c)].  With bias_out (f32 [N]) the bias gradient
     bias_out (+)= colsum(dy) is produced by the same launch when the kernel supports it (returns True); otherwise the
     caller has to run colsum (returns False)."""
@@ -197,6 +199,7 @@ def gemm_wgrad(dy: torch.Tensor, a: torch.Tensor, slabs: torch.Tensor, M: int, N
     if bias_out is not None and bias_slabs is not None and N.lib().theia_wgrad_fuses_bias(g, _dt(dy)):
         assert bias_slabs.numel() >= splits * Nn and bias_out.dtype == torch.float32
         g.bias_slabs, g.bias_out, g.bias_accumulate = bias_slabs.data_ptr(), bias_out.data_ptr(), int(bias_accumulate)
+        g.defer_bias_reduce = int(defer_bias)  # the bias partials are then reduced by wgrad_finish, in the weights' launch
         fused = True
     if WGRAD_PROFILE is not None:  # tuning aid (bench.py THEIA_BENCH_GEMM_TABLE): HIP events on the launch stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -217,6 +220,15 @@ def wgrad_reduce(slabs: torch.Tensor, splits: int, Nn: int, kslots: int, C: int,
                  accumulate: bool) -> None:
     N.check(N.lib().theia_wgrad_reduce(slabs.data_ptr(), splits, Nn, kslots, C, out.data_ptr(), sn, ss, sc, int(accumulate),
                                        N.stream_ptr()), "theia_wgrad_reduce")
+
+
+def wgrad_finish(slabs: torch.Tensor, splits: int, Nn: int, kslots: int, C: int, out: torch.Tensor, sn: int, ss: int, sc: int,
+                 accumulate: bool, bias: Optional[Tuple[torch.Tensor, torch.Tensor, bool]] = None) -> None:
+    """out (reference layout) (+)= sum over the split slabs, both sides coalesced; bias = (bias_slabs, bias_out, accumulate) reduces
+    the bias partials of the same weight-gradient GEMM in the same launch."""
+    bs, bo, ba = (bias[0].data_ptr(), bias[1].data_ptr(), int(bias[2])) if bias is not None else (None, None, 0)
+    N.check(N.lib().theia_wgrad_finish(slabs.data_ptr(), splits, Nn, kslots, C, out.data_ptr(), sn, ss, sc, int(accumulate), bs, bo, ba,
+                                       N.stream_ptr()), "theia_wgrad_finish")
 
 
 def conv_wgrad_splits(plan: ConvPlan, b: int, C: int) -> int:
@@ -245,14 +257,14 @@ def conv_wgrad(plan: ConvPlan, dy: torch.Tensor, x: torch.Tensor, b: int, C: int
     if plan.wgrad_swapped:
         rmap, mpi = plan.dgrad
         gemm_wgrad(x, dy, slabs, b * mpi, C, C, 9, splits, rmap)
-        wgrad_reduce(slabs, splits, C, 9, C, grad_w, 9 * C, 1, 9, accumulate)  # slab[ci][tap][co] -> W[ci, co, ky, kx]
+        wgrad_finish(slabs, splits, C, 9, C, grad_w, 9 * C, 1, 9, accumulate)  # slab[ci][tap][co] -> W[ci, co, ky, kx]
     else:
         for k, (rmap, mpi) in enumerate(plan.fwd):
             one = len(plan.fwd) == 1 and bias is not None
             fused = gemm_wgrad(dy, x, slabs, b * mpi, C, C, 9, splits, rmap, bias[0] if one else None, bias[1] if one else False,
-                               ws[need:need + extra] if one else None)
+                               ws[need:need + extra] if one else None, defer_bias=True)
         sn, ss, sc = plan.grad_strides
-        wgrad_reduce(slabs, splits, C, 9, C, grad_w, sn, ss, sc, accumulate)
+        wgrad_finish(slabs, splits, C, 9, C, grad_w, sn, ss, sc, accumulate, (ws[need:need + extra], bias[0], bias[1]) if fused else None)
     if bias is not None and not fused:
         colsum(dy.view(-1, C), bias[0], bias[1], ws)
 
@@ -269,8 +281,8 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, grad_w: torch.Tensor, accumu
     if ws is None or ws.numel() < need + extra:
         ws = torch.empty(need + extra, dtype=torch.float32, device=dy.device)
     fused = gemm_wgrad(dy, x, ws, M, Nn, dy.stride(0), 1, splits, rm_plain(K, x.stride(0), dy.stride(0)),
-                       bias[0] if bias is not None else None, bias[1] if bias is not None else False, ws[need:need + extra])
-    wgrad_reduce(ws, splits, Nn, 1, K, grad_w, K, 0, 1, accumulate)
+                       bias[0] if bias is not None else None, bias[1] if bias is not None else False, ws[need:need + extra], defer_bias=True)
+    wgrad_finish(ws, splits, Nn, 1, K, grad_w, K, 0, 1, accumulate, (ws[need:need + extra], bias[0], bias[1]) if fused else None)
     if bias is not None and not fused:
         colsum(dy, bias[0], bias[1], ws)
 
@@ -355,6 +367,11 @@ def unpermute3(src: torch.Tensor, dst: torch.Tensor, d0: int, d1: int, d2: int, 
                                          N.stream_ptr()), "theia_unpermute3_f32")
 
 
+def transpose_acc(src: torch.Tensor, dst: torch.Tensor, R: int, Cc: int, accumulate: bool) -> None:
+    """dst[c*R + r] (+)= src[r*C + c] (f32)"""
+    N.check(N.lib().theia_transpose_acc_f32(src.data_ptr(), dst.data_ptr(), R, Cc, int(accumulate), N.stream_ptr()), "theia_transpose_acc_f32")
+
+
 def resize_u8(img: torch.Tensor, channels_last: bool, out_h: int, out_w: int, resample: int = 2) -> torch.Tensor:
     """uint8 [b,H,W,3] / [b,3,H,W] on the GPU -> uint8 [b,out_h,out_w,3]: Image.resize((out_w, out_h), resample) of Pillow."""
     from .preprocess import resize_plan
@@ -411,11 +428,17 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dresid, dgamma, dbeta, accumulate: b
     return dx
 
 
-def layernorm_chw_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, ws: Optional[torch.Tensor] = None):
-    """x [b, E] (NHWC flattened); gamma/beta f32 [E] in NHWC order."""
+def layernorm_chw_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, ws: Optional[torch.Tensor] = None,
+                      sums: Optional[torch.Tensor] = None):
+    """x [b, E] (NHWC flattened); gamma/beta f32 [E] in NHWC order.  sums: f32 [b, 2] per-sample (sum, sum of squares) of x already
+    accumulated by the producing GEMM's epilogue (gemm_nt(..., ln_sums=)) -> one pass instead of three."""
     b, E = x.shape
     y = torch.empty_like(x)
     stats = torch.empty(b, 2, dtype=torch.float32, device=x.device)
+    if sums is not None:
+        N.check(N.lib().theia_layernorm_chw_fwd_sums(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), sums.data_ptr(),
+                                                     stats.data_ptr(), b, E, eps, _dt(x), N.stream_ptr()), "theia_layernorm_chw_fwd_sums")
+        return y, stats
     need = N.lib().theia_layernorm_chw_workspace_bytes(b, E) // 4
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.float32, device=x.device)
