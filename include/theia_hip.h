@@ -29,7 +29,10 @@ extern "C" {
 #define THEIA_ABI_VERSION 3
 
 enum { THEIA_OK = 0, THEIA_ERR_INVALID = -1, THEIA_ERR_LAUNCH = -2, THEIA_ERR_UNSUPPORTED = -3 };
-enum { THEIA_F32 = 0, THEIA_BF16 = 1 };
+enum { THEIA_F32 = 0, THEIA_BF16 = 1,
+       /* theia_gemm_nt only: operands A and W are OCP fp8 e4m3 bytes (quantised with theia_quantize_fp8, per-tensor scales),
+        * accumulation is f32 on the fp8 matrix cores, the output / residual / aux tensors and every epilogue are bf16 */
+       THEIA_FP8 = 2 };
 
 int theia_abi_version(void);
 const char* theia_last_error(void);
@@ -114,6 +117,10 @@ typedef struct theia_gemm_args {
      * zeroes the buffer before the first launch that writes the tensor (the 4 output-parity launches of a stride-2 transposed
      * convolution add into the same sums). */
     float* ln_sums;
+    /* THEIA_FP8: device pointers to the de-quantisation factors 1/scale of the two operands (one f32 each); the accumulator is
+     * multiplied by their product before the epilogue.  NULL = 1. */
+    const float* a_scale_inv;
+    const float* w_scale_inv;
 } theia_gemm_args_t;
 
 int theia_gemm_nt(const theia_gemm_args_t* args, int dtype, void* stream);
@@ -169,6 +176,14 @@ int theia_wgrad_finish(const float* slabs, int splits, int N, int kslots, int C,
 int theia_colsum(const void* x, int64_t M, int N, int64_t ld, float* out, float* workspace, int accumulate,
                  int dtype, void* stream);
 size_t theia_colsum_workspace_bytes(int64_t M, int N);
+
+/* fp8 (OCP e4m3) quantisation with per-tensor delayed scaling, for THEIA_FP8 GEMM operands (BASELINE configs[3]):
+ *   dst[r*C + c] = e4m3( clamp(src[r*ld + c] * *scale, +-448) ),   *amax = max(*amax, max |src|)   (src: THEIA_F32 / THEIA_BF16)
+ * theia_fp8_update_scales turns the amax collected during a step into the scales of the next one:
+ *   scale[i] = 448 / (amax[i] * margin) (unchanged when amax[i] == 0), inv_scale[i] = 1 / scale[i], amax[i] = 0. */
+int theia_quantize_fp8(const void* src, int src_dtype, int64_t rows, int C, int64_t ld, uint8_t* dst, const float* scale, float* amax,
+                       void* stream);
+int theia_fp8_update_scales(float* amax, float* scale, float* inv_scale, int n, float margin, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Parameter preparation (fp32 master weights in the reference state_dict layout -> operand layouts)

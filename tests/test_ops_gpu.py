@@ -659,3 +659,84 @@ def test_transpose_acc_and_wgrad_finish_layouts():
             got = view(out).reshape(Nn_, kslots, C)
             assert relerr(got, want + (0.25 if acc else 0.0)) < 1e-6
             assert relerr(bout, bpart.sum(0) + (0.25 if acc else 0.0)) < 1e-6
+
+
+def test_fp8_quantize_and_scale_update():
+    """theia_quantize_fp8 == torch's float8_e4m3fn rounding of the scaled, saturated values (bit for bit), amax tracking and
+    the delayed-scaling update."""
+    from theia_amd import ops
+    dev = _dev()
+    x = torch.cat([h((300, 200), 3, 5.0), torch.tensor([[1000.0, -1000.0, 448.0, -448.0, 0.0, 1e-4, 0.0019, 0.001] * 25])], 0)
+    for dt in (torch.float32, torch.bfloat16):
+        xr = rnd(x, dt)
+        amax = torch.zeros(1, device=dev)
+        for sc in (1.0, 0.37, 90.0):
+            scale = torch.tensor([sc], device=dev)
+            q = ops.quantize_fp8(x.to(dev, dt), scale, amax)
+            ref = (xr * sc).clamp(-448, 448).to(torch.float8_e4m3fn)
+            assert torch.equal(q.cpu().view(torch.uint8), ref.view(torch.uint8)), (dt, sc)
+        assert float(amax) == float(xr.abs().max())
+        wide = torch.zeros(301, 264, dtype=dt, device=dev)
+        wide[:, 64:] = x.to(dev, dt)
+        q = ops.quantize_fp8(wide[:, 64:], torch.ones(1, device=dev))  # strided rows, no amax
+        assert torch.equal(q.cpu().view(torch.uint8), xr.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
+    amax = torch.tensor([2.0, 0.0, 56.0], device=dev)
+    scale, inv = torch.ones(3, device=dev), torch.ones(3, device=dev)
+    ops.fp8_update_scales(amax, scale, inv, 1.0)
+    assert scale.tolist() == [224.0, 1.0, 8.0] and inv.tolist() == [1 / 224.0, 1.0, 0.125] and amax.tolist() == [0.0, 0.0, 0.0]
+
+
+@pytest.mark.parametrize("M,N,K", [(2600, 768, 768), (513, 264, 128), (256 * 5, 512, 64), (25216, 1152, 384)])
+def test_fp8_gemm_against_dequantised_reference(M, N, K):
+    """THEIA_FP8 theia_gemm_nt: e4m3 operands, f32 accumulation on the fp8 matrix cores, bf16 epilogues -- against an f32 GEMM
+    of the DE-QUANTISED operands (so the only differences are accumulation order and the bf16 output rounding, tolerance 2e-2),
+    for the epilogues the engine uses."""
+    from theia_amd import ops, _native as Nn
+    dev = _dev()
+    x, w = h((M, K), 1, 2.0), h((N, K), 2, 1.0 / math.sqrt(K))
+    bias, res = h((N,), 3, 0.1), h((M, N), 4, 1.0)
+    sx, sw = torch.tensor([448.0 / float(x.abs().max())], device=dev), torch.tensor([448.0 / float(w.abs().max())], device=dev)
+    x8, w8 = ops.quantize_fp8(x.to(dev), sx), ops.quantize_fp8(w.to(dev), sw)
+    inv = (1.0 / sx, 1.0 / sw)
+    ref = (x8.float().cpu() @ w8.float().cpu().t()) * float(inv[0]) * float(inv[1])
+    # the quantisation itself: within e4m3's 2^-4 relative step of the exact product (sanity, not a kernel property)
+    assert relerr(ref, x @ w.t()) < 0.1
+    y = ops.linear(x8, w8, bias.to(dev), scale_inv=inv)
+    assert y.dtype == torch.bfloat16 and relerr(y.float(), ref + bias) < TOL[torch.bfloat16]
+    y = ops.linear(x8, w8, bias.to(dev), resid=res.to(dev, torch.bfloat16), scale_inv=inv)
+    assert relerr(y.float(), ref + bias + rnd(res, torch.bfloat16)) < TOL[torch.bfloat16]
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    y = ops.linear(x8, w8, bias.to(dev), act=Nn.ACT_GELU, aux_out=pre, scale_inv=inv)
+    assert relerr(pre.float(), ref + bias) < TOL[torch.bfloat16]
+    assert relerr(y.float(), torch.nn.functional.gelu(ref + bias)) < TOL[torch.bfloat16]
+    with pytest.raises(Nn.TheiaNativeError, match="fp8"):
+        ops.linear(x8[:, :40].contiguous(), w8[:, :40].contiguous(), scale_inv=inv)  # K = 40 is not a multiple of 64
+
+
+@pytest.mark.parametrize("kind", ["conv_p1", "convT_s2_op1"])
+def test_fp8_implicit_gemm_convolutions(kind):
+    """fp8 operands through the row-map gather (3x3 convolution, stride-2 transposed convolution parity classes + data-gradient)."""
+    from theia_amd import ops, _native as Nn
+    dev = _dev()
+    b, C = 3, 128
+    IH = {"conv_p1": 16, "convT_s2_op1": 31}[kind]
+    x = h((b, IH, IH, C), 21, 1.0)
+    W = h((C, C, 3, 3), 22, 1.0 / math.sqrt(9 * C))
+    bias = h((C,), 23, 0.1)
+    plan = ops.plan_conv3x3(C, IH) if kind == "conv_p1" else ops.plan_convT3x3(C, IH, 2, 0, 1)
+    OH = plan.out_hw
+    one = torch.ones(1, device=dev)
+    sx, sw = 448.0 / float(x.abs().max()), 448.0 / float(W.abs().max())
+    x8 = ops.quantize_fp8(x.view(-1, C).to(dev), one * sx).view(b, IH, IH, C)
+    wf = _pack(plan.pack_fwd, W, torch.float32, dev).view(C, 9 * C)
+    wf8 = ops.quantize_fp8(wf, one * sw)
+    xq = x8.float().cpu() / sx
+    Wq = (_pack(plan.pack_fwd, W, torch.float32, dev).view(C, 9 * C)).cpu()
+    # de-quantised weights back in the reference layout: quantisation is element-wise, so quantise the original tensor
+    Wdq = (W * sw).clamp(-448, 448).to(torch.float8_e4m3fn).float() / sw
+    ref = O.conv3x3_p1(xq, Wdq, bias) if kind == "conv_p1" else O.convT3x3(xq, Wdq, bias, 2, 0, 1)
+    out = torch.empty(b, OH, OH, C, dtype=torch.bfloat16, device=dev)
+    inv = (one / sx, one / sw)
+    for rmap, mpi in plan.fwd:
+        ops.gemm_nt(x8, wf8, out, b * mpi, C, rmap.ntaps * C, rmap, 9 * C, C, bias=bias.to(dev), scale_inv=inv)
+    assert relerr(out.float(), ref) < TOL[torch.bfloat16]

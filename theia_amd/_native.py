@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede CDLL: provides libamdhip64)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtheia_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 ABI_VERSION = 3
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_MUL_DGELU, ACT_MUL_DRELU = 0, 1, 2, 3, 4
 MAX_TAPS = 9
@@ -47,6 +47,7 @@ class GemmArgs(C.Structure):
         ("map", RowMap),
         ("tile", C.c_int32), ("reserved", C.c_int32),
         ("ln_sums", C.c_void_p),
+        ("a_scale_inv", C.c_void_p), ("w_scale_inv", C.c_void_p),
     ]
 
 
@@ -85,6 +86,8 @@ _SIGNATURES = {
     "theia_wgrad_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "theia_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "theia_quantize_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "theia_fp8_update_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "theia_colsum_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "theia_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "theia_cast_batch_plan": (C.c_int64, [C.c_void_p, C.c_int]),
@@ -166,6 +169,8 @@ def dtype_code(t: torch.dtype) -> int:
         return F32
     if t == torch.bfloat16:
         return BF16
+    if t == torch.float8_e4m3fn:  # THEIA_FP8: theia_gemm_nt operands only
+        return FP8
     raise TypeError(f"unsupported dtype {t}")
 
 

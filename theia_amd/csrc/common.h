@@ -46,6 +46,10 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector((theia_f32x2_v){lo, hi}, theia_bf16x2_v));
 }
 
+// fp8 (OCP e4m3) operand bytes of the THEIA_FP8 GEMM path: a distinct 1-byte type so that templates can tell it from uint8 pixels
+struct fp8_t { uint8_t bits; };
+static_assert(sizeof(fp8_t) == 1, "fp8_t is one byte");
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int kPer16B = 4;

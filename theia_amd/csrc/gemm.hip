@@ -289,10 +289,18 @@ static int gemm_nt_plan(const theia_gemm_args_t* a, int dtype) {
         e = getenv("THEIA_CONV_KERNEL");
         use_conv = (e != nullptr && strcmp(e, "std") == 0) ? 0 : 1;
     }
-    const int hkt = dtype == THEIA_BF16 ? 32 : 16;  // k elements of one half-tile of the ping-pong kernels
-    const bool pp_ok = a->K % hkt == 0 && a->map.in_c % hkt == 0 &&
-                       (int64_t)a->map.in_c * (dtype == THEIA_BF16 ? 2 : 4) <= 16384;  // one tap's row fits the kernel's zero page
-    const bool conv_ok = theia_gemm_conv_pp_match(a, dtype, nullptr);
+    const int hkt = dtype == THEIA_FP8 ? 64 : dtype == THEIA_BF16 ? 32 : 16;  // k elements of one half-tile of the ping-pong kernels
+    const int esz = dtype == THEIA_FP8 ? 1 : dtype == THEIA_BF16 ? 2 : 4;
+    const bool pp_ok = a->K % hkt == 0 && a->map.in_c % hkt == 0 && (int64_t)a->map.in_c * esz <= 16384;  // one tap's row fits the zero page
+    const bool conv_ok = dtype != THEIA_FP8 && theia_gemm_conv_pp_match(a, dtype, nullptr);
+    if (dtype == THEIA_FP8) {  // fp8 operands exist for the ping-pong kernel only
+        if (!pp_ok || (a->tile != 0 && a->tile != 256256)) {
+            theia_set_error("theia_gemm_nt(fp8): needs K and in_c multiples of 64 and the 256x256 ping-pong kernel (K=%d in_c=%d tile=%d)", a->K,
+                            a->map.in_c, a->tile);
+            return THEIA_ERR_UNSUPPORTED;
+        }
+        return 256256;
+    }
     if (a->tile == 256256 && !pp_ok) {
         theia_set_error("theia_gemm_nt: the 256x256 ping-pong kernel needs K and in_c multiples of %d and in_c <= %d (K=%d in_c=%d)", hkt,
                         dtype == THEIA_BF16 ? 8192 : 4096, a->K, a->map.in_c);
@@ -312,16 +320,16 @@ static int gemm_nt_plan(const theia_gemm_args_t* a, int dtype) {
 }
 
 extern "C" int theia_gemm_nt_plan(const theia_gemm_args_t* a, int dtype) {
-    THEIA_CHECK_ARG(a != nullptr && (dtype == THEIA_F32 || dtype == THEIA_BF16), "theia_gemm_nt_plan: bad arguments");
+    THEIA_CHECK_ARG(a != nullptr && (dtype == THEIA_F32 || dtype == THEIA_BF16 || dtype == THEIA_FP8), "theia_gemm_nt_plan: bad arguments");
     return gemm_nt_plan(a, dtype);
 }
 
 extern "C" int theia_gemm_nt(const theia_gemm_args_t* a, int dtype, void* stream) {
     THEIA_CHECK_ARG(a != nullptr, "theia_gemm_nt: null args");
-    THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16, "theia_gemm_nt: bad dtype %d", dtype);
+    THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16 || dtype == THEIA_FP8, "theia_gemm_nt: bad dtype %d", dtype);
     THEIA_CHECK_ARG(a->a && a->w && a->out, "theia_gemm_nt: null operand pointer");
     THEIA_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "theia_gemm_nt: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
-    const int epc = dtype == THEIA_BF16 ? 8 : 4;
+    const int epc = dtype == THEIA_FP8 ? 16 : dtype == THEIA_BF16 ? 8 : 4;
     THEIA_CHECK_ARG(a->N % 8 == 0, "theia_gemm_nt: N=%d must be a multiple of 8", a->N);
     THEIA_CHECK_ARG(a->K % epc == 0 && a->ldw % epc == 0, "theia_gemm_nt: K=%d / ldw=%d must be multiples of %d", a->K, a->ldw, epc);
     THEIA_CHECK_ARG(a->K == a->map.ntaps * a->map.in_c, "theia_gemm_nt: K=%d != ntaps*in_c=%d", a->K, a->map.ntaps * a->map.in_c);
@@ -333,7 +341,7 @@ extern "C" int theia_gemm_nt(const theia_gemm_args_t* a, int dtype, void* stream
     THEIA_CHECK_ARG((a->act != THEIA_ACT_MUL_DGELU && a->act != THEIA_ACT_MUL_DRELU) || a->aux_in, "theia_gemm_nt: act needs aux_in");
     THEIA_CHECK_ARG(a->rowtab == nullptr || a->rowtab_period > 0, "theia_gemm_nt: rowtab_period");
     THEIA_CHECK_ARG(a->ln_sums == nullptr || a->map.rows_h * a->map.rows_w >= 128, "theia_gemm_nt: ln_sums needs >= 128 rows per image");
-    int rc = check_rowmap(a->map, dtype == THEIA_BF16 ? 64 : 32, "theia_gemm_nt");
+    int rc = check_rowmap(a->map, dtype == THEIA_F32 ? 32 : 64, "theia_gemm_nt");
     if (rc) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int plan = gemm_nt_plan(a, dtype);

@@ -273,7 +273,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
 
     PP_PHASE(4)
     float* ep = reinterpret_cast<float*>(smem) + wave * (64 * (WN + 4));
-    gt_epilogue<T, WM, WN, SUMS>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
+    if constexpr (sizeof(T) == 1) gt_epilogue<bf16_t, WM, WN, SUMS, true>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);  // fp8 operands, bf16 out
+    else gt_epilogue<T, WM, WN, SUMS>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
     PP_PHASE(5)
 #ifdef PP_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -298,7 +299,16 @@ int theia_gemm_nt_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t s
         cxx_reads = (e != nullptr && strcmp(e, "cxx") == 0) ? 1 : 0;
         if (cxx_reads) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
-    if (a->ln_sums != nullptr) {
+    if (dtype == THEIA_FP8) {  // fp8 e4m3 operands (bytes), bf16 output
+        static bool attr8 = false;
+        if (!attr8) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<fp8_t, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<fp8_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr8 = true;
+        }
+        if (a->ln_sums != nullptr) hipLaunchKernelGGL((gemm_nt_pp_kernel<fp8_t, false, true>), dim3(tiles), dim3(512), lds, stream, *a);
+        else hipLaunchKernelGGL((gemm_nt_pp_kernel<fp8_t, false, false>), dim3(tiles), dim3(512), lds, stream, *a);
+    } else if (a->ln_sums != nullptr) {
         static bool attr2 = false;
         if (!attr2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<bf16_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

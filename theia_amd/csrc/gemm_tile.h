@@ -28,6 +28,13 @@ template <> struct GtMma<float> {
 template <typename T> __device__ __forceinline__ void gt_mma(gt_f32x4& acc, const gt_u32x4& a, const gt_u32x4& b) {
     if constexpr (sizeof(T) == 2) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gt_bf16x8, a), __builtin_bit_cast(gt_bf16x8, b), acc, 0, 0, 0);
+    } else if constexpr (sizeof(T) == 1) {
+        // fp8 e4m3: a 16-byte chunk = two k-steps of 8 bytes per lane; both operands split their chunk the same way, so the
+        // contraction is over the same 16 k whatever the instruction's internal k order
+        const long a0 = (long)(((unsigned long)a[1] << 32) | a[0]), a1 = (long)(((unsigned long)a[3] << 32) | a[2]);
+        const long b0 = (long)(((unsigned long)b[1] << 32) | b[0]), b1 = (long)(((unsigned long)b[3] << 32) | b[2]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, acc, 0, 0, 0);
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[k]), __uint_as_float(b[k]), acc, 0, 0, 0);
@@ -106,7 +113,8 @@ template <typename T> __device__ __forceinline__ float gt_gelu_grad(float x) {
 // duration (29-36k cycles per 256x256 tile; tools/pp_trace.hip).
 // SUMS: also accumulate p.ln_sums (a separate instantiation, launched only for the GEMMs that feed a whole-sample LayerNorm, so
 // that every other launch pays nothing for it)
-template <typename T, int WM, int WN, bool SUMS = false, int GPMAX = 4>
+// SCALE: multiply the accumulators by (*p.a_scale_inv) * (*p.w_scale_inv) first (fp8 operands: T is then the OUTPUT type, bf16)
+template <typename T, int WM, int WN, bool SUMS = false, bool SCALE = false, int GPMAX = 4>
 __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], float* ep /* wave-private LDS */,
                                             const theia_gemm_args_t& p, int m_wave0, int n_wave0, int lane) {
     constexpr int FM = WM / 16, FN = WN / 16;
@@ -130,6 +138,8 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
     for (int j = 0; j < 8; ++j) bias8[j] = 0.f;
     if (p.bias != nullptr && n_ok) load8(p.bias + n, bias8);
     const int act = p.act;
+    float alpha = 1.0f;
+    if constexpr (SCALE) alpha = (p.a_scale_inv != nullptr ? *p.a_scale_inv : 1.0f) * (p.w_scale_inv != nullptr ? *p.w_scale_inv : 1.0f);
     const bool want_aux = act == THEIA_ACT_MUL_DGELU || act == THEIA_ACT_MUL_DRELU;
     const T* __restrict__ PRE = want_aux ? AUXI : RES;  // the row that is prefetched (bf16 path)
     const bool pre_on = sizeof(T) == 2 && PRE != nullptr;
@@ -225,7 +235,7 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
             float v[8];
             load8(ep + row * EP_PITCH + col, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += bias8[j];
+            for (int j = 0; j < 8; ++j) v[j] = (SCALE ? v[j] * alpha : v[j]) + bias8[j];
             if (p.rowtab != nullptr) {
                 const int m = m_wave0 + lrow + (g * GP + q) * RPP;
                 float t8[8];

@@ -212,6 +212,72 @@ extern "C" int theia_unpermute3_f32(const float* src, float* dst, int d0, int d1
     return THEIA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) quantisation with per-tensor delayed scaling: operands of the THEIA_FP8 GEMM path (BASELINE configs[3]).
+// HBM-bound: reads 2 (bf16) or 4 (f32) bytes, writes 1 per element.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* __restrict__ src, int64_t rows, int C, int64_t ld, uint8_t* __restrict__ dst,
+                                                           const float* __restrict__ scale, float* __restrict__ amax) {
+    __shared__ float red[4];
+    const float sc = *scale;
+    const int cv = C / 8;
+    const int64_t nvec = rows * cv;
+    float am = 0.f;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+        const int64_t r = v / cv;
+        const int c = (int)(v - r * cv) * 8;
+        float x[8];
+        load8(src + r * ld + c, x);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            am = fmaxf(am, fabsf(x[j]));
+            x[j] = fminf(fmaxf(x[j] * sc, -448.f), 448.f);  // e4m3fn has no infinity: saturate
+        }
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(x[4], x[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(x[6], x[7], hi, true);
+        *reinterpret_cast<uint2*>(dst + r * C + c) = make_uint2(lo, hi);
+    }
+    am = wave_max(am);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0 && amax != nullptr) {
+        am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(am));  // non-negative floats order like their bit patterns
+    }
+}
+extern "C" int theia_quantize_fp8(const void* src, int src_dtype, int64_t rows, int C, int64_t ld, uint8_t* dst, const float* scale,
+                                  float* amax, void* stream) {
+    THEIA_CHECK_ARG(src && dst && scale && rows > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0, "theia_quantize_fp8: bad args (C and ld multiples of 8)");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int g = grid_for(rows * (C / 8), 256, 8192);
+    DISPATCH_T(src_dtype, hipLaunchKernelGGL(quantize_fp8_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)src, rows, C, ld, dst, scale, amax),
+               hipLaunchKernelGGL(quantize_fp8_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)src, rows, C, ld, dst, scale, amax),
+               "theia_quantize_fp8");
+    THEIA_CHECK_LAUNCH("theia_quantize_fp8");
+    return THEIA_OK;
+}
+__global__ void fp8_update_scales_kernel(float* __restrict__ amax, float* __restrict__ scale, float* __restrict__ inv_scale, int n, float margin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = amax[i];
+    if (a > 0.f && a < INFINITY) {
+        const float sc = 448.f / (a * margin);
+        scale[i] = sc;
+        inv_scale[i] = 1.0f / sc;
+    }
+    amax[i] = 0.f;
+}
+extern "C" int theia_fp8_update_scales(float* amax, float* scale, float* inv_scale, int n, float margin, void* stream) {
+    THEIA_CHECK_ARG(amax && scale && inv_scale && n > 0 && margin > 0.f, "theia_fp8_update_scales: bad args");
+    hipLaunchKernelGGL(fp8_update_scales_kernel, dim3(cdiv_i(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), amax, scale, inv_scale, n, margin);
+    THEIA_CHECK_LAUNCH("theia_fp8_update_scales");
+    return THEIA_OK;
+}
+
 // dst[c*R + r] (+)= src[r*C + c]: f32 matrix transpose through a 32x33 LDS tile (both sides coalesced).  The LayerNorm[C,H,W]
 // affine gradients are reduced in the NHWC order of the activations ([HW][C]) and live in the reference's [C][HW] order.
 __global__ __launch_bounds__(256) void transpose_acc_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C,

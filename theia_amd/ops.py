@@ -133,7 +133,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int
             bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, act: int = N.ACT_NONE,
             aux_in: Optional[torch.Tensor] = None, aux_out: Optional[torch.Tensor] = None,
             rowtab: Optional[torch.Tensor] = None, rowtab_period: int = 0, tile: int = 0, plan_only: bool = False,
-            ln_sums: Optional[torch.Tensor] = None):
+            ln_sums: Optional[torch.Tensor] = None, scale_inv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """tile: kernel request (0 = the library's choice; see theia_gemm_args_t.tile).  plan_only: launch nothing, return the code
     of the kernel the library would run (theia_gemm_nt_plan)."""
     g = GemmArgs()
@@ -143,7 +143,12 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int
     g.M, g.N, g.K, g.ldw, g.ldo, g.act = M, Nn, K, ldw, ldo, act
     g.map = rmap
     g.ln_sums = N.ptr(ln_sums)  # f32 [images, 2], zeroed by the caller: += (sum, sum of squares) of each image's stored outputs
-    if tile == 0 and GEMM_TILE_HINT != 0:
+    if a.dtype == torch.float8_e4m3fn:  # fp8 operands (quantize_fp8), bf16 output: de-quantisation factors as device scalars
+        assert w.dtype == torch.float8_e4m3fn and out.dtype == torch.bfloat16
+        if scale_inv is not None:
+            g.a_scale_inv, g.w_scale_inv = scale_inv[0].data_ptr(), scale_inv[1].data_ptr()
+        tile = 0 if tile in (0, 256256) else tile
+    if tile == 0 and GEMM_TILE_HINT != 0 and a.dtype != torch.float8_e4m3fn:
         if GEMM_TILE_HINT == 128128:
             tile = 128128 if N.lib().theia_gemm_nt_tile(M, Nn, _dt(a)) != 128064 else 0
         elif N.lib().theia_gemm_nt_tile(M, Nn, _dt(a)) != 128064:  # 256256: every ping-pong kernel the problem admits
@@ -153,7 +158,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int
             elif pp_supported(K, rmap.in_c, a.dtype):
                 tile = 256256
     g.tile = tile
-    assert a.dtype == w.dtype == out.dtype
+    assert a.dtype == w.dtype and (a.dtype == out.dtype or a.dtype == torch.float8_e4m3fn)
     if plan_only:
         return N.lib().theia_gemm_nt_plan(g, _dt(a))
     if GEMM_PROFILE is not None:  # bench.py: HIP events on the launch stream around every theia_gemm_nt launch
@@ -169,14 +174,31 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
            act: int = N.ACT_NONE, aux_in: Optional[torch.Tensor] = None, aux_out: Optional[torch.Tensor] = None,
-           out: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
-    """out = act(x @ w.T + bias) + resid ; x [M,K], w [N,K] contiguous."""
+           out: Optional[torch.Tensor] = None, tile: int = 0, scale_inv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+    """out = act(x @ w.T + bias) + resid ; x [M,K], w [N,K] contiguous.  fp8 operands (float8_e4m3fn, with scale_inv) -> bf16 out."""
     M, K = x.shape
     Nn = w.shape[0]
     if out is None:
-        out = torch.empty(M, Nn, dtype=x.dtype, device=x.device)
+        out = torch.empty(M, Nn, dtype=torch.bfloat16 if x.dtype == torch.float8_e4m3fn else x.dtype, device=x.device)
     return gemm_nt(x, w, out, M, Nn, K, rm_plain(K, x.stride(0), out.stride(0)), w.stride(0), out.stride(0), bias, resid, act,
-                   aux_in, aux_out, tile=tile)
+                   aux_in, aux_out, tile=tile, scale_inv=scale_inv)
+
+
+def quantize_fp8(x: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [rows, C] (bf16 / f32, row stride x.stride(0)) -> float8_e4m3fn [rows, C] = e4m3(clamp(x * *scale, +-448)); *amax = max(*amax, max|x|).
+    scale / amax: 1-element f32 device tensors (views into the engine's scale tables)."""
+    rows, Cc = x.shape
+    if out is None:
+        out = torch.empty(rows, Cc, dtype=torch.float8_e4m3fn, device=x.device)
+    N.check(N.lib().theia_quantize_fp8(x.data_ptr(), _dt(x), rows, Cc, x.stride(0), out.data_ptr(), scale.data_ptr(), N.ptr(amax), N.stream_ptr()),
+            "theia_quantize_fp8")
+    return out
+
+
+def fp8_update_scales(amax: torch.Tensor, scale: torch.Tensor, inv_scale: torch.Tensor, margin: float = 1.0) -> None:
+    """delayed scaling: scale = 448 / (amax * margin) for every slot that saw data, inv_scale = 1 / scale, amax = 0"""
+    N.check(N.lib().theia_fp8_update_scales(amax.data_ptr(), scale.data_ptr(), inv_scale.data_ptr(), amax.numel(), margin, N.stream_ptr()),
+            "theia_fp8_update_scales")
 
 
 def _wgrad_args(dy: torch.Tensor, a: torch.Tensor, slabs: torch.Tensor, M: int, Nn: int, ldo: int, kslots: int, splits: int,
