@@ -436,3 +436,27 @@ def test_interpolated_position_embeddings_match_reference(golden_dir, tag, bb):
     # same images through the default path (processor resize to 224): 196 patch tokens again
     with torch.no_grad():
         assert model.forward_feature(img).shape[1] == (195 if tag == "nocls" else 196)
+
+
+@pytest.mark.parametrize("bb", ["facebook/deit-tiny-patch16-224", "facebook/deit-small-patch16-224"])
+def test_fp8_mode_tracks_the_oracle(bb):
+    """precision="fp8" (BASELINE configs[3]: e4m3 operands with per-tensor delayed scaling for the forward and data-gradient
+    GEMMs, bf16 activations / epilogues / weight-gradient GEMMs, f32 accumulation) against the CPU oracle's fp32 losses and
+    gradients.  Stated tolerance: losses 5e-2 relative, per-tensor gradient cosine > 0.9 (e4m3 carries 3 mantissa bits: ~6 %
+    per operand element, averaged down by the K-long dot products)."""
+    teachers, B = O.TEACHER_SETS["cddsv"], 4
+    model, params = build(bb, teachers, "fp8")
+    images = O.synth_images(B, 0)
+    tcpu = O.synth_targets(B, teachers, 1)
+    targets = {t: v.to("cuda:0") for t, v in tcpu.items()}
+    for _ in range(2):  # second pass: every quantisation site has a calibrated scale and re-uses it
+        model.zero_grad(set_to_none=True)
+        losses = model.get_loss(model(images), targets)
+        (0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]).backward()
+    assert model.engine.fp8 is not None and len(model.engine.fp8.index) > 100
+    ref_losses, _, grads, _ = O.train_step_grads(params, images, tcpu, bb, teachers, "cos_l1")
+    for k in ("mse_loss", "cos_loss", "l1_loss"):
+        assert rel(float(losses[k]), float(ref_losses[k])) < 5e-2, (k, float(losses[k]), float(ref_losses[k]))
+    cos, nr, who = _grad_agreement(model, grads)
+    print(f"[fp8 {bb}] worst gradient cosine {cos:.4f} ({who}), worst norm-ratio error {nr:.3f}")
+    assert cos > 0.9 and nr < 0.15, (cos, nr, who)

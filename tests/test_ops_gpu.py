@@ -683,7 +683,8 @@ def test_fp8_quantize_and_scale_update():
     amax = torch.tensor([2.0, 0.0, 56.0], device=dev)
     scale, inv = torch.ones(3, device=dev), torch.ones(3, device=dev)
     ops.fp8_update_scales(amax, scale, inv, 1.0)
-    assert scale.tolist() == [224.0, 1.0, 8.0] and inv.tolist() == [1 / 224.0, 1.0, 0.125] and amax.tolist() == [0.0, 0.0, 0.0]
+    assert scale.tolist() == [224.0, 1.0, 8.0] and amax.tolist() == [0.0, 0.0, 0.0]
+    assert inv.tolist() == pytest.approx([1 / 224.0, 1.0, 0.125], rel=1e-6)
 
 
 @pytest.mark.parametrize("M,N,K", [(2600, 768, 768), (513, 264, 128), (256 * 5, 512, 64), (25216, 1152, 384)])
@@ -710,7 +711,7 @@ def test_fp8_gemm_against_dequantised_reference(M, N, K):
     assert relerr(pre.float(), ref + bias) < TOL[torch.bfloat16]
     assert relerr(y.float(), torch.nn.functional.gelu(ref + bias)) < TOL[torch.bfloat16]
     with pytest.raises(Nn.TheiaNativeError, match="fp8"):
-        ops.linear(x8[:, :40].contiguous(), w8[:, :40].contiguous(), scale_inv=inv)  # K = 40 is not a multiple of 64
+        ops.linear(x8[:, :48].contiguous(), w8[:, :48].contiguous(), scale_inv=inv)  # K = 48 is not a multiple of 64
 
 
 @pytest.mark.parametrize("kind", ["conv_p1", "convT_s2_op1"])

@@ -116,6 +116,45 @@ def bicubic_matrix(n_in: int, n_out: int, scale: float) -> np.ndarray:
     return m
 
 
+class Fp8Scales:
+    """Per-tensor delayed scaling of the fp8 (e4m3) GEMM operands (precision="fp8", BASELINE configs[3]).  One slot per
+    quantisation site (an activation / gradient tensor at a fixed place of the step, or a weight operand): the quantiser records
+    max|x| into `amax` while it quantises with the scale derived from the PREVIOUS step's maximum; `update()` (once per step,
+    when the operand cache is rebuilt after the optimizer) turns the maxima into the next scales on the device -- no host
+    round trip.  A site's very first use calibrates itself with an extra max-only pass."""
+
+    def __init__(self, device, capacity: int = 2048):
+        self.amax = torch.zeros(capacity, dtype=torch.float32, device=device)
+        self.scale = torch.ones(capacity, dtype=torch.float32, device=device)
+        self.inv = torch.ones(capacity, dtype=torch.float32, device=device)
+        self.index: Dict[str, int] = {}
+        self.calibrated: set = set()
+
+    def slot(self, site: str) -> int:
+        i = self.index.get(site)
+        if i is None:
+            i = self.index[site] = len(self.index)
+            if i >= self.amax.numel():
+                raise RuntimeError("Fp8Scales: out of slots")
+        return i
+
+    def quantize(self, x2d: torch.Tensor, site: str):
+        """-> (float8_e4m3fn [rows, C], inv_scale view)"""
+        i = self.slot(site)
+        sc, am, inv = self.scale[i:i + 1], self.amax[i:i + 1], self.inv[i:i + 1]
+        if site not in self.calibrated:  # first use: max-only pass, then this slot's scale
+            q = ops.quantize_fp8(x2d, sc, am)
+            ops.fp8_update_scales(am, sc, inv)
+            self.calibrated.add(site)
+            return ops.quantize_fp8(x2d, sc, am, out=q), inv
+        return ops.quantize_fp8(x2d, sc, am), inv
+
+    def update(self) -> None:
+        n = len(self.index)
+        if n:
+            ops.fp8_update_scales(self.amax[:n], self.scale[:n], self.inv[:n])
+
+
 class _SideQueue:
     """A second HIP stream (+ its own scratch) for work whose results are only needed at the end of backward.
 
@@ -222,11 +261,13 @@ class GradBucket:
 
 class StudentEngine:
     def __init__(self, rvfm, precision: str = "fp32"):
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' (exact-f32 MFMA, parity mode) or 'bf16' (throughput mode)")
+        if precision not in ("fp32", "bf16", "fp8"):
+            raise ValueError("precision must be 'fp32' (exact-f32 MFMA, parity mode), 'bf16' (throughput mode) or 'fp8' (bf16 "
+                             "activations, e4m3 operands for the forward / data-gradient GEMMs, bf16 weight-gradient GEMMs)")
         self.rvfm = rvfm
         self.dtype = torch.float32 if precision == "fp32" else torch.bfloat16
         self.precision = precision
+        self.fp8: Optional[Fp8Scales] = None  # created with the operand table (needs the device)
         vit = rvfm.backbone.model
         self.D, self.heads, self.F = vit.hidden_size, vit.num_heads, vit.intermediate_size
         self.tok0, self.nreg = (1 if vit.has_cls else 0), vit.num_reg_tokens  # token layout of the student (nocls- / reg-)
@@ -383,9 +424,28 @@ class StudentEngine:
         if ptr_key != self._op_ptr_key:
             self._opcache, self._opbatch = self._build_operand_table(device)
             self._op_ptr_key = ptr_key
+            if self.precision == "fp8":
+                self.fp8 = Fp8Scales(device)
         self._opbatch.run()
+        if self.fp8 is not None:
+            # delayed scaling: last step's maxima become this step's scales; then the e4m3 copies of every GEMM weight operand
+            # (forward W and data-gradient W^T / packed convolution weights) are re-quantised from their bf16 operands
+            self.fp8.update()
+            for k in [k for k, t in self._opcache.items() if t.dtype == torch.bfloat16 and t.dim() == 2 and not k.endswith(".f8")
+                      and t.shape[1] % 64 == 0 and t.shape[0] >= 64 and k != "patch.w"]:
+                q, inv = self.fp8.quantize(self._opcache[k], "w:" + k)
+                self._opcache[k + ".f8"], self._opcache[k + ".inv"] = q, inv
         self._opkey = key
         return self._opcache
+
+    def _mm(self, x: torch.Tensor, key: str, bias: Optional[torch.Tensor] = None, **epi) -> torch.Tensor:
+        """x [M, K] @ operand `key`^T with the epilogue `epi`: fp8 operands when the engine runs in fp8 mode and the operand has an
+        e4m3 copy (K a multiple of 64, N >= 64), bf16 / f32 otherwise."""
+        oc = self._opcache
+        if self.fp8 is not None and key + ".f8" in oc and "out" not in epi:
+            x8, inv = self.fp8.quantize(x, "x:" + key)
+            return ops.linear(x8, oc[key + ".f8"], bias, scale_inv=(inv, oc[key + ".inv"]), **epi)
+        return ops.linear(x, oc[key], bias, **epi)
 
     def _build_operand_table(self, device):
         T, D, F = self.dtype, self.D, self.F
@@ -521,13 +581,13 @@ class StudentEngine:
         saved: Dict[str, Any] = {"b": b, "geo": geo, "patches": patches if save else None, "layers": []}
         for i, L in enumerate(vit.layers):
             a, mean1, rstd1 = ops.layernorm_fwd(h, L.layernorm_before.weight, L.layernorm_before.bias, LN_EPS_VIT)
-            qkv = ops.linear(a, oc[f"l{i}.wqkv"], oc[f"l{i}.bqkv"])
+            qkv = self._mm(a, f"l{i}.wqkv", oc[f"l{i}.bqkv"])
             o, lse = ops.attention_fwd(qkv, b, NTOK, nh)
-            h1 = ops.linear(o, oc[f"l{i}.wo"], L.attention.o_proj.bias, resid=h)
+            h1 = self._mm(o, f"l{i}.wo", L.attention.o_proj.bias, resid=h)
             m, mean2, rstd2 = ops.layernorm_fwd(h1, L.layernorm_after.weight, L.layernorm_after.bias, LN_EPS_VIT)
             pre = torch.empty(M, F, dtype=T, device=dev) if save else None
-            act = ops.linear(m, oc[f"l{i}.w1"], L.mlp.fc1.bias, act=N.ACT_GELU, aux_out=pre)
-            h2 = ops.linear(act, oc[f"l{i}.w2"], L.mlp.fc2.bias, resid=h1)
+            act = self._mm(m, f"l{i}.w1", L.mlp.fc1.bias, act=N.ACT_GELU, aux_out=pre)
+            h2 = self._mm(act, f"l{i}.w2", L.mlp.fc2.bias, resid=h1)
             if save:
                 saved["layers"].append((h, mean1, rstd1, a, qkv, o, lse, h1, mean2, rstd2, m, pre, act))
             h = h2
@@ -575,10 +635,10 @@ class StudentEngine:
             saved["layers"][i] = None
             # h2 = h1 + fc2(act)
             wgrad(dh, act, L.mlp.fc2.weight, L.mlp.fc2.bias)
-            dpre = ops.linear(dh, oc[f"l{i}.w2T"], None, act=N.ACT_MUL_DGELU, aux_in=pre)
+            dpre = self._mm(dh, f"l{i}.w2T", None, act=N.ACT_MUL_DGELU, aux_in=pre)
             del act, pre
             wgrad(dpre, m, L.mlp.fc1.weight, L.mlp.fc1.bias)
-            dm = ops.linear(dpre, oc[f"l{i}.w1T"])
+            dm = self._mm(dpre, f"l{i}.w1T")
             del dpre
             g2w, acc = self._grad(L.layernorm_after.weight)
             g2b, _ = self._grad(L.layernorm_after.bias)
@@ -586,13 +646,13 @@ class StudentEngine:
             del dm, dh
             # h1 = h + o_proj(o)
             wgrad(dh1, o, L.attention.o_proj.weight, L.attention.o_proj.bias)
-            do = ops.linear(dh1, oc[f"l{i}.woT"])
+            do = self._mm(dh1, f"l{i}.woT")
             dqkv = ops.attention_bwd(qkv, o, do, lse, b, NTOK, nh, ws)
             del do
             for j, prj in enumerate((L.attention.q_proj, L.attention.k_proj, L.attention.v_proj)):
                 sl = dqkv[:, j * D:(j + 1) * D]
                 wgrad(sl, a, prj.weight, prj.bias)
-            da = ops.linear(dqkv, oc[f"l{i}.wqkvT"])
+            da = self._mm(dqkv, f"l{i}.wqkvT")
             del dqkv
             g1w, acc = self._grad(L.layernorm_before.weight)
             g1b, _ = self._grad(L.layernorm_before.bias)
@@ -671,10 +731,22 @@ class StudentEngine:
         """sums: zeroed f32 [b, 2]; every launch (4 output-parity classes for a stride-2 transposed convolution) adds the per-sample
         (sum, sum of squares) of what it stores: the statistics of the whole-sample LayerNorm that follows."""
         C = self.D
+        wf, scale_inv = self._conv_operands(x, wf)
+        if scale_inv is not None:
+            x = scale_inv[2]
         for rmap, mpi in plan.fwd:
             ops.gemm_nt(x, wf, out, b * mpi, C, rmap.ntaps * C, rmap, 9 * C, C, bias=bias, act=N.ACT_RELU if relu else N.ACT_NONE,
-                        ln_sums=sums)
+                        ln_sums=sums, scale_inv=scale_inv[:2] if scale_inv is not None else None)
         return out
+
+    def _conv_operands(self, x: torch.Tensor, wkey: str):
+        """(weight operand, None) -- or in fp8 mode (e4m3 weight, (inv_x, inv_w, e4m3 activation)): the activation (any NHWC /
+        token layout with C channels innermost) is quantised as a [rows, C] matrix, the row map addresses it unchanged"""
+        oc = self._opcache
+        if self.fp8 is not None and wkey + ".f8" in oc:
+            x8, inv = self.fp8.quantize(x.reshape(-1, self.D), "x:" + wkey)
+            return oc[wkey + ".f8"], (inv, oc[wkey + ".inv"], x8)
+        return oc[wkey], None
 
     def _translator_fwd(self, z: torch.Tensor, names: List[str], save: bool):
         dev, T, C = z.device, self.dtype, self.D
@@ -699,16 +771,16 @@ class StudentEngine:
             chw_ws = self.ws(N.lib().theia_layernorm_chw_workspace_bytes(b, s2 * s2 * C) // 4, dev)
             sums = torch.zeros(3, b, 2, dtype=torch.float32, device=dev)  # LayerNorm statistics out of the convolutions' epilogues
             u1 = torch.empty(b, 256 * C, dtype=T, device=dev)
-            self._conv_fwd(z, oc[pf + "pad.wf"], hm.pad["1"].bias, self._plan("pad"), b, u1, relu=False, sums=sums[0])
+            self._conv_fwd(z, pf + "pad.wf", hm.pad["1"].bias, self._plan("pad"), b, u1, relu=False, sums=sums[0])
             v1, st0 = ops.layernorm_chw_fwd(u1, oc[pf + "ln0.g"], oc[pf + "ln0.b"], LN_EPS_HEAD, chw_ws, sums=sums[0])
             p1, p4 = ("up31", "up64") if hm.kind == "up64" else ("conv16", "conv16")
             u2 = torch.empty(b, s1 * s1 * C, dtype=T, device=dev)
-            self._conv_fwd(v1, oc[pf + "c1.wf"], hm.adapter["1"].bias, self._plan(p1), b, u2, relu=True, sums=sums[1])
+            self._conv_fwd(v1, pf + "c1.wf", hm.adapter["1"].bias, self._plan(p1), b, u2, relu=True, sums=sums[1])
             v2, st3 = ops.layernorm_chw_fwd(u2, oc[pf + "ln3.g"], oc[pf + "ln3.b"], LN_EPS_HEAD, chw_ws, sums=sums[1])
             u3 = torch.empty(b, s2 * s2 * C, dtype=T, device=dev)
-            self._conv_fwd(v2, oc[pf + "c4.wf"], hm.adapter["4"].bias, self._plan(p4), b, u3, relu=True, sums=sums[2])
+            self._conv_fwd(v2, pf + "c4.wf", hm.adapter["4"].bias, self._plan(p4), b, u3, relu=True, sums=sums[2])
             v3, st6 = ops.layernorm_chw_fwd(u3, oc[pf + "ln6.g"], oc[pf + "ln6.b"], LN_EPS_HEAD, chw_ws, sums=sums[2])
-            pred = ops.linear(v3.view(b * s2 * s2, C), oc[pf + "w8"], hm.adapter["8"].bias)
+            pred = self._mm(v3.view(b * s2 * s2, C), pf + "w8", hm.adapter["8"].bias)
             outs.append(pred.view(b, s2 * s2, -1))
             if save:
                 saved.append((u1, st0, v1, u2, st3, v2, u3, st6, v3))
@@ -793,29 +865,31 @@ class StudentEngine:
                     ops.transpose_acc(tmp_b, g, hw * hw, C, acc)
                 return dx
 
-            def conv_dgrad(dy, wd, plan, out, resid=None):
+            def conv_dgrad(dy, wd_key, plan, out, resid=None):
                 rmap, mpi = plan.dgrad
-                ops.gemm_nt(dy, wd, out, b * mpi, C, 9 * C, rmap, 9 * C, C, resid=resid)
+                wd, scale_inv = self._conv_operands(dy, wd_key)
+                ops.gemm_nt(dy if scale_inv is None else scale_inv[2], wd, out, b * mpi, C, 9 * C, rmap, 9 * C, C, resid=resid,
+                            scale_inv=scale_inv[:2] if scale_inv is not None else None)
                 return out
 
             p1, p4 = ("up31", "up64") if hm.kind == "up64" else ("conv16", "conv16")
             lin_grads(dp, v3.view(b * s2 * s2, C), hm.adapter["8"])
-            dv3 = ops.linear(dp, oc[pf + "w8T"])
+            dv3 = self._mm(dp, pf + "w8T")
             del v3
             du3 = ln_bwd(dv3.view(b, E3), u3, st6, "6", s2, True)
             del dv3, u3
             conv_grads(du3.view(b * s2 * s2, C), v2, hm.adapter["4"], self._plan(p4), b * s2 * s2)
-            dv2 = conv_dgrad(du3, oc[pf + "c4.wd"], self._plan(p4), torch.empty(b, s1 * s1 * C, dtype=T, device=dev))
+            dv2 = conv_dgrad(du3, pf + "c4.wd", self._plan(p4), torch.empty(b, s1 * s1 * C, dtype=T, device=dev))
             del du3, v2
             du2 = ln_bwd(dv2, u2, st3, "3", s1, True)
             del dv2, u2
             conv_grads(du2.view(b * s1 * s1, C), v1, hm.adapter["1"], self._plan(p1), b * s1 * s1)
-            dv1 = conv_dgrad(du2, oc[pf + "c1.wd"], self._plan(p1), torch.empty(b, 256 * C, dtype=T, device=dev))
+            dv1 = conv_dgrad(du2, pf + "c1.wd", self._plan(p1), torch.empty(b, 256 * C, dtype=T, device=dev))
             del du2, v1
             du1 = ln_bwd(dv1, u1, st0, "0", s0, False)
             del dv1, u1
             conv_grads(du1.view(b * 256, C), z, hm.pad["1"], self._plan("pad"), b * 256)
-            conv_dgrad(du1, oc[pf + "pad.wd"], self._plan("pad"), dz, resid=dz)
+            conv_dgrad(du1, pf + "pad.wd", self._plan("pad"), dz, resid=dz)
             del du1
             if train:
                 self._bucket_done(bucket, side)

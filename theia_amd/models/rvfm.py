@@ -4,7 +4,8 @@ forward / backward run in hand-written HIP kernels on MI355X.
 Same constructor signature, attributes, methods (``forward_feature``, ``forward``, ``get_loss``,
 ``load_pretrained_weights``, ``freeze_translator``) and state_dict keys as the reference; one extra keyword,
 ``precision`` ("fp32": exact-f32 MFMA path, reference-parity mode and the default; "bf16": bf16 MFMA operands with
-f32 accumulation and f32 master weights, the throughput mode).
+f32 accumulation and f32 master weights, the throughput mode; "fp8": the bf16 mode with OCP e4m3 operands, per-tensor
+delayed scaling, for every forward / data-gradient GEMM -- BASELINE configs[3]).
 """
 from __future__ import annotations
 

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--tile", type=int, default=0, help="kernel request for theia_gemm_nt (0 = library's choice)")
+    ap.add_argument("--fp8", action="store_true", help="fp8 e4m3 operands (plain shapes, nt only)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     T = torch.bfloat16
@@ -62,9 +63,17 @@ def main():
             w = (torch.randn(N, K, device=dev) * 0.02).to(T)
             out = torch.empty(M, N, dtype=T, device=dev)
 
-            def run_nt():
-                ops.linear(x, w, out=out, tile=a.tile)
-            kern = ops.KERNEL_NAMES.get(a.tile or ops.N.lib().theia_gemm_nt_tile(M, N, 1))
+            if a.fp8:
+                one = torch.ones(1, device=dev)
+                x8, w8 = ops.quantize_fp8(x, one), ops.quantize_fp8(w, one * 20)
+
+                def run_nt():
+                    ops.linear(x8, w8, out=out, scale_inv=(one, one))
+                kern = "256x256-fp8"
+            else:
+                def run_nt():
+                    ops.linear(x, w, out=out, tile=a.tile)
+                kern = ops.KERNEL_NAMES.get(a.tile or ops.N.lib().theia_gemm_nt_tile(M, N, 1))
             dy = torch.randn(M, N, device=dev).to(T)
             g = torch.empty(N, K, dtype=torch.float32, device=dev)
             ws = torch.empty(ops.wgrad_splits(M, N, K) * N * K, dtype=torch.float32, device=dev)
@@ -72,7 +81,7 @@ def main():
             def run_wg():
                 ops.linear_wgrad(dy, x, g, False, ws)
         for label, fn in (("nt", run_nt), ("wgrad", run_wg)):
-            if a.what not in (label, "both") or (label == "wgrad" and kind in ("conv_dgrad", "pad")):
+            if a.what not in (label, "both") or (label == "wgrad" and (kind in ("conv_dgrad", "pad") or a.fp8)):
                 continue
             for _ in range(3):
                 fn()
