@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o pmc -- \
-      python $REPO/bench.py --steps 2 --warmup 1 --no-roofline --no-cpu-baseline > $OUT/$c.log 2>&1
+      python $REPO/bench.py --steps 2 --warmup 1 --no-roofline --no-cpu-baseline --no-selfcheck > $OUT/$c.log 2>&1
 done
 python $REPO/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
 python - "$OUT/summary.txt" <<'PY'
@@ -22,6 +22,14 @@ for block in re.split(r"\n(?=\S)", txt):
         # guide (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts wide streaming reads at half their bytes on gfx950 -> x2; KB units
         out[lines[0].strip()] = {"fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
                                  "hbm_bytes_per_launch": round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)}
+# hash of the NT kernel sources the counters were taken from: bench.py only reports `roofline.traffic` from a summary whose
+# hash matches the sources it runs (otherwise the number would silently go stale)
+import hashlib, os
+root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+h = hashlib.sha256()
+for f in ("theia_amd/csrc/gemm_pp.hip", "theia_amd/csrc/gemm_tile.h", "theia_amd/csrc/gemm.hip"):
+    h.update(open(os.path.join(root, f), "rb").read())
+out["_kernel_src_sha"] = h.hexdigest()[:16]
 json.dump(out, open(sys.argv[1].replace("summary.txt", "traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if "gemm" in k}, indent=1))
 PY
