@@ -29,7 +29,7 @@ __device__ __forceinline__ uint4 wp_tr_frag(const char* __restrict__ part, int l
     return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 
-__global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_args_t p) {
+__global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_args_t p, const int allow_fast) {
     constexpr int NSTAGE = 4, MS = 32, ROWB = 512, PART = MS * ROWB, STAGE = 2 * PART;
     constexpr int FM = 8, FN = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -75,22 +75,66 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
         st_ry[i] = rem / mp.rows_w;
         st_rx[i] = rem - st_ry[i] * mp.rows_w;
     }
+    // Fast row stepping (wave-uniform choice): when 32 rows are a whole number of images (plain matrices: R = 1) or of image rows
+    // (rows_w divides 32 and 32 / rows_w <= rows_h: the 16x16 maps of the 3x3 convolutions), the two source addresses of a staged
+    // row advance by constants, plus one constant when the row index wraps into the next image -- ~20 VALU instructions per
+    // staged row instead of ~70 for the general decode below (PMC, round 1: 5.8 VALU instructions per MFMA in this kernel,
+    // issued between the MFMAs of the M segment; 3.6x the NT kernel's).
+    const int R_img = mp.rows_h * mp.rows_w;
+    const bool whole_images = (MS % R_img) == 0;
+    const bool fast = allow_fast && (whole_images || ((MS % mp.rows_w) == 0 && MS / mp.rows_w <= mp.rows_h));
+    const int RS = whole_images ? 0 : MS / mp.rows_w;  // image rows per step
+    const int64_t oy_step = whole_images ? (int64_t)(MS / R_img) * mp.out_batch_stride : (int64_t)RS * mp.out_sy * mp.out_w * p.ldo;
+    const int64_t ox_step = whole_images ? (int64_t)(MS / R_img) * mp.in_batch_stride : (int64_t)RS * mp.in_sy * mp.in_w * mp.in_c;
+    const int64_t oy_wrap = mp.out_batch_stride - (int64_t)mp.rows_h * mp.out_sy * mp.out_w * p.ldo;  // extra step when ry wraps
+    const int64_t ox_wrap = mp.in_batch_stride - (int64_t)mp.rows_h * mp.in_sy * mp.in_w * mp.in_c;
+    uint64_t f_py[2], f_px[2];   // element addresses of the row's dY / activation piece (valid or not)
+    bool f_xok[2];               // the tap's column is inside the image (constant per staged row)
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t oy = (int64_t)st_img[i] * mp.out_batch_stride + mp.out_offset +
+                               (int64_t)((st_ry[i] * mp.out_sy + mp.out_y0) * mp.out_w + st_rx[i] * mp.out_sx + mp.out_x0) * p.ldo + n0 + col;
+            const int iy = st_ry[i] * mp.in_sy + dy, ix = st_rx[i] * mp.in_sx + dx;
+            const int64_t ox = (int64_t)st_img[i] * mp.in_batch_stride + mp.in_offset + (int64_t)(iy * mp.in_w + ix) * mp.in_c + c0 + col;
+            f_py[i] = reinterpret_cast<uint64_t>(DY + oy);
+            f_px[i] = reinterpret_cast<uint64_t>(A + ox);
+            f_xok[i] = (ix >= 0) & (ix < mp.in_w);
+        }
+    }
     // issue the dY piece and the activation piece of row i for the current half-step, then advance the row by 32
     auto issue_row = [&](int i, char* slot) {
         const bool mok = st_m[i] < m_limit;
-        const int64_t oy = (int64_t)st_img[i] * mp.out_batch_stride + mp.out_offset +
-                           (int64_t)((st_ry[i] * mp.out_sy + mp.out_y0) * mp.out_w + st_rx[i] * mp.out_sx + mp.out_x0) * p.ldo + n0 + col;
-        const int iy = st_ry[i] * mp.in_sy + dy, ix = st_rx[i] * mp.in_sx + dx;
-        const bool xok = mok & (iy >= 0) & (iy < mp.in_h) & (ix >= 0) & (ix < mp.in_w);
-        const int64_t ox = (int64_t)st_img[i] * mp.in_batch_stride + mp.in_offset + (int64_t)(iy * mp.in_w + ix) * mp.in_c + c0 + col;
-        const uint64_t my = 0ull - (uint64_t)(mok & n_ok), mx = 0ull - (uint64_t)xok;
-        const uint64_t sy = (reinterpret_cast<uint64_t>(DY + oy) & my) | (zp & ~my);
-        const uint64_t sx = (reinterpret_cast<uint64_t>(A + ox) & mx) | (zp & ~mx);
+        uint64_t sy, sx;
+        if (fast) {
+            const int iy = st_ry[i] * mp.in_sy + dy;
+            const bool xok = mok & f_xok[i] & (iy >= 0) & (iy < mp.in_h);
+            const uint64_t my = 0ull - (uint64_t)(mok & n_ok), mx = 0ull - (uint64_t)xok;
+            sy = (f_py[i] & my) | (zp & ~my);
+            sx = (f_px[i] & mx) | (zp & ~mx);
+        } else {
+            const int64_t oy = (int64_t)st_img[i] * mp.out_batch_stride + mp.out_offset +
+                               (int64_t)((st_ry[i] * mp.out_sy + mp.out_y0) * mp.out_w + st_rx[i] * mp.out_sx + mp.out_x0) * p.ldo + n0 + col;
+            const int iy = st_ry[i] * mp.in_sy + dy, ix = st_rx[i] * mp.in_sx + dx;
+            const bool xok = mok & (iy >= 0) & (iy < mp.in_h) & (ix >= 0) & (ix < mp.in_w);
+            const int64_t ox = (int64_t)st_img[i] * mp.in_batch_stride + mp.in_offset + (int64_t)(iy * mp.in_w + ix) * mp.in_c + c0 + col;
+            const uint64_t my = 0ull - (uint64_t)(mok & n_ok), mx = 0ull - (uint64_t)xok;
+            sy = (reinterpret_cast<uint64_t>(DY + oy) & my) | (zp & ~my);
+            sx = (reinterpret_cast<uint64_t>(A + ox) & mx) | (zp & ~mx);
+        }
         char* dst = slot + (16 * i + uwave * 2) * ROWB;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sy, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx, (__attribute__((address_space(3))) void*)(dst + PART), 16, 0, 0);
-        // advance: m += 32  ->  (rx, ry, img) with float-reciprocal wraps (operands < 2^12, one correction each)
         st_m[i] += MS;
+        if (fast) {  // constants per step; one more constant when the image row index wraps
+            int ry = st_ry[i] + RS;
+            const bool wrap = ry >= mp.rows_h;  // never true for whole_images (RS = 0, ry stays 0)
+            st_ry[i] = wrap ? ry - mp.rows_h : ry;
+            f_py[i] += (uint64_t)(oy_step + (wrap ? oy_wrap : 0)) * sizeof(bf16_t);
+            f_px[i] += (uint64_t)(ox_step + (wrap ? ox_wrap : 0)) * sizeof(bf16_t);
+            return;
+        }
+        // general advance: m += 32  ->  (rx, ry, img) with float-reciprocal wraps (operands < 2^12, one correction each)
         int rx = st_rx[i] + MS;
         int q = (int)((float)rx * rcpW);
         rx -= q * mp.rows_w;
@@ -219,7 +263,12 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
         attr_set = true;
     }
     const int tiles = cdiv_i(a->N, 256) * a->map.ntaps * (a->map.in_c / 256);
-    hipLaunchKernelGGL(gemm_wgrad_pp_kernel, dim3(tiles * a->splits), dim3(512), lds, stream, *a);
+    static int allow_fast = -1;  // THEIA_WGRAD_STEP=general: A/B switch for the row-stepping fast path
+    if (allow_fast < 0) {
+        const char* e = getenv("THEIA_WGRAD_STEP");
+        allow_fast = (e != nullptr && strcmp(e, "general") == 0) ? 0 : 1;
+    }
+    hipLaunchKernelGGL(gemm_wgrad_pp_kernel, dim3(tiles * a->splits), dim3(512), lds, stream, *a, allow_fast);
     THEIA_CHECK_LAUNCH("theia_gemm_wgrad(pp)");
     if (a->bias_out != nullptr && a->defer_bias_reduce == 0) {
         hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv_i(a->N, 256)), dim3(256), 0, stream, a->bias_slabs, a->splits, a->N,
