@@ -29,7 +29,9 @@ __device__ __forceinline__ uint4 wp_tr_frag(const char* __restrict__ part, int l
     return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 
-__global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_args_t p, const int allow_fast) {
+// FAST: constant-step row addressing (see below); the host picks the instantiation, so the hot loop carries one path only
+template <bool FAST>
+__global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_args_t p) {
     constexpr int NSTAGE = 4, MS = 32, ROWB = 512, PART = MS * ROWB, STAGE = 2 * PART;
     constexpr int FM = 8, FN = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     // issued between the MFMAs of the M segment; 3.6x the NT kernel's).
     const int R_img = mp.rows_h * mp.rows_w;
     const bool whole_images = (MS % R_img) == 0;
-    const bool fast = allow_fast && (whole_images || ((MS % mp.rows_w) == 0 && MS / mp.rows_w <= mp.rows_h));
+    constexpr bool fast = FAST;  // host: whole_images || (32 % rows_w == 0 && 32 / rows_w <= rows_h)
     const int RS = whole_images ? 0 : MS / mp.rows_w;  // image rows per step
     const int64_t oy_step = whole_images ? (int64_t)(MS / R_img) * mp.out_batch_stride : (int64_t)RS * mp.out_sy * mp.out_w * p.ldo;
     const int64_t ox_step = whole_images ? (int64_t)(MS / R_img) * mp.in_batch_stride : (int64_t)RS * mp.in_sy * mp.in_w * mp.in_c;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     const int64_t ox_wrap = mp.in_batch_stride - (int64_t)mp.rows_h * mp.in_sy * mp.in_w * mp.in_c;
     uint64_t f_py[2], f_px[2];   // element addresses of the row's dY / activation piece (valid or not)
     bool f_xok[2];               // the tap's column is inside the image (constant per staged row)
-    if (fast) {
+    if constexpr (fast) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int64_t oy = (int64_t)st_img[i] * mp.out_batch_stride + mp.out_offset +
@@ -106,12 +108,11 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     auto issue_row = [&](int i, char* slot) {
         const bool mok = st_m[i] < m_limit;
         uint64_t sy, sx;
-        if (fast) {
+        if constexpr (fast) {
             const int iy = st_ry[i] * mp.in_sy + dy;
             const bool xok = mok & f_xok[i] & (iy >= 0) & (iy < mp.in_h);
-            const uint64_t my = 0ull - (uint64_t)(mok & n_ok), mx = 0ull - (uint64_t)xok;
-            sy = (f_py[i] & my) | (zp & ~my);
-            sx = (f_px[i] & mx) | (zp & ~mx);
+            sy = (mok & n_ok) ? f_py[i] : zp;
+            sx = xok ? f_px[i] : zp;
         } else {
             const int64_t oy = (int64_t)st_img[i] * mp.out_batch_stride + mp.out_offset +
                                (int64_t)((st_ry[i] * mp.out_sy + mp.out_y0) * mp.out_w + st_rx[i] * mp.out_sx + mp.out_x0) * p.ldo + n0 + col;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sy, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx, (__attribute__((address_space(3))) void*)(dst + PART), 16, 0, 0);
         st_m[i] += MS;
-        if (fast) {  // constants per step; one more constant when the image row index wraps
+        if constexpr (fast) {  // constants per step; one more constant when the image row index wraps
             int ry = st_ry[i] + RS;
             const bool wrap = ry >= mp.rows_h;  // never true for whole_images (RS = 0, ry stays 0)
             st_ry[i] = wrap ? ry - mp.rows_h : ry;
@@ -259,7 +260,8 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
     constexpr int lds = 4 * 2 * 32 * 512;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int tiles = cdiv_i(a->N, 256) * a->map.ntaps * (a->map.in_c / 256);
@@ -268,7 +270,10 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
         const char* e = getenv("THEIA_WGRAD_STEP");
         allow_fast = (e != nullptr && strcmp(e, "general") == 0) ? 0 : 1;
     }
-    hipLaunchKernelGGL(gemm_wgrad_pp_kernel, dim3(tiles * a->splits), dim3(512), lds, stream, *a, allow_fast);
+    const int R_img = a->map.rows_h * a->map.rows_w;
+    const bool fast = allow_fast && ((32 % R_img) == 0 || ((32 % a->map.rows_w) == 0 && 32 / a->map.rows_w <= a->map.rows_h));
+    if (fast) hipLaunchKernelGGL(gemm_wgrad_pp_kernel<true>, dim3(tiles * a->splits), dim3(512), lds, stream, *a);
+    else hipLaunchKernelGGL(gemm_wgrad_pp_kernel<false>, dim3(tiles * a->splits), dim3(512), lds, stream, *a);
     THEIA_CHECK_LAUNCH("theia_gemm_wgrad(pp)");
     if (a->bias_out != nullptr && a->defer_bias_reduce == 0) {
         hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv_i(a->N, 256)), dim3(256), 0, stream, a->bias_slabs, a->splits, a->N,
