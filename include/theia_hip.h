@@ -111,8 +111,9 @@ typedef struct theia_gemm_args {
      * cross-checks the automatic choice against a forced one). */
     int32_t tile;
     int32_t reserved;
-    /* optional: f32 [images][2], accumulated ATOMICALLY with (sum, sum of squares) of the stored output values of each image
-     * (image = GEMM row / (rows_h*rows_w), needs rows_h*rows_w >= 128).  The whole-sample LayerNorm that follows a translator
+    /* optional: int64 [images][2] (declared float* for ABI stability: 16 bytes per image), accumulated atomically with the
+     * 2^-24 fixed-point (sum, sum of squares) of the stored output values of each image -- integer adds, so the result does not
+     * depend on arrival order -- (image = GEMM row / (rows_h*rows_w), needs rows_h*rows_w >= 128).  The whole-sample LayerNorm that follows a translator
      * convolution (adapter_heads.py:306-324) takes its statistics from here instead of re-reading the activation; the caller
      * zeroes the buffer before the first launch that writes the tensor (the 4 output-parity launches of a stride-2 transposed
      * convolution add into the same sums). */
@@ -269,7 +270,8 @@ size_t theia_layernorm_bwd_workspace_bytes(int64_t M, int D);
  * ---------------------------------------------------------------------------------------------- */
 int theia_layernorm_chw_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
                             float* workspace, int b, int64_t E, float eps, int dtype, void* stream);
-/* the same with the per-sample (sum, sum of squares) already known (theia_gemm_args_t.ln_sums of the producing GEMM): one pass,
+/* the same with the per-sample (sum, sum of squares) already known (theia_gemm_args_t.ln_sums of the producing GEMM: int64
+ * fixed point, passed as const float*): one pass,
  * 4 B/element in bf16 instead of 6; writes stats (mean, rstd) for the backward pass */
 int theia_layernorm_chw_fwd_sums(const void* x, const float* gamma, const float* beta, void* y, const float* sums, float* stats,
                                  int b, int64_t E, float eps, int dtype, void* stream);

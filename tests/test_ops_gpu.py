@@ -619,11 +619,16 @@ def test_conv_epilogue_emits_layernorm_statistics(dt, kind, tile):
     OH = plan.out_hw
     xd, wf = x.to(dev, dt), _pack(plan.pack_fwd, W, dt, dev)
     out = torch.zeros(b, OH, OH, C, dtype=dt, device=dev)
-    sums = torch.zeros(b, 2, dtype=torch.float32, device=dev)
+    sums = torch.zeros(b, 2, dtype=torch.int64, device=dev)  # 2^-24 fixed point: order-independent integer accumulation
     for rmap, mpi in plan.fwd:
         ops.gemm_nt(xd, wf, out, b * mpi, C, rmap.ntaps * C, rmap, 9 * C, C, bias=bias.to(dev), act=Nn.ACT_RELU, tile=tile, ln_sums=sums)
     o64 = out.double().view(b, -1)
-    assert relerr(sums[:, 0], o64.sum(1)) < 1e-5 and relerr(sums[:, 1], (o64 * o64).sum(1)) < 1e-5
+    fsum = sums.double() / 2 ** 24
+    assert relerr(fsum[:, 0], o64.sum(1)) < 1e-5 and relerr(fsum[:, 1], (o64 * o64).sum(1)) < 1e-5
+    again = torch.zeros_like(sums)
+    for rmap, mpi in plan.fwd:
+        ops.gemm_nt(xd, wf, out, b * mpi, C, rmap.ntaps * C, rmap, 9 * C, C, bias=bias.to(dev), act=Nn.ACT_RELU, tile=tile, ln_sums=again)
+    assert torch.equal(again, sums)  # bit-reproducible
     E = OH * OH * C
     g = (h((E,), 52, 0.2) + 1.0).to(dev)
     s_ = h((E,), 53, 0.2).to(dev)

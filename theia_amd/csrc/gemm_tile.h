@@ -174,7 +174,7 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
     gt_u32x4 npre[GP];
     // optional per-image (sum, sum of squares) of the stored values (theia_gemm_args_t.ln_sums): a wave tile of WM <= 128 rows
     // touches at most two images (rows per image >= 128, checked by the dispatch): slot 0 = the image of the tile's first row
-    float* const lsum = SUMS ? p.ln_sums : nullptr;
+    unsigned long long* const lsum = SUMS ? reinterpret_cast<unsigned long long*>(p.ln_sums) : nullptr;
     int img0, dummy_rem;
     img0 = gt_divmod(m_wave0 < p.M ? m_wave0 : 0, R, rcp_R, dummy_rem);
     const int m_split = (img0 + 1) * R;  // first GEMM row of the second image
@@ -299,12 +299,15 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
         lq0 = wave_sum(lq0);
         ls1 = wave_sum(ls1);
         lq1 = wave_sum(lq1);
+        // 2^-24 fixed point in 64-bit integers: integer addition is associative, so the totals do not depend on the order in
+        // which the waves arrive (bit-reproducible steps; float atomics were not), and a wave's partial loses < 6e-8 absolute
+        auto fx = [](float v) { return (unsigned long long)__double2ll_rn((double)v * 16777216.0); };
         if (lane == 0 && m_wave0 < p.M) {
-            atomicAdd(lsum + 2 * img0, ls0);
-            atomicAdd(lsum + 2 * img0 + 1, lq0);
+            atomicAdd(lsum + 2 * img0, fx(ls0));
+            atomicAdd(lsum + 2 * img0 + 1, fx(lq0));
             if ((int64_t)(img0 + 1) * R < p.M) {  // a second image exists (its sums are zero when the tile did not reach it)
-                atomicAdd(lsum + 2 * (img0 + 1), ls1);
-                atomicAdd(lsum + 2 * (img0 + 1) + 1, lq1);
+                atomicAdd(lsum + 2 * (img0 + 1), fx(ls1));
+                atomicAdd(lsum + 2 * (img0 + 1) + 1, fx(lq1));
             }
         }
     }

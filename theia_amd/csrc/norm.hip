@@ -321,9 +321,10 @@ __global__ __launch_bounds__(256) void chw_apply_kernel(const T* __restrict__ x,
                                                         float eps = 0.f) {
     const int sample = blockIdx.y;
     float mu, rs;
-    if constexpr (SUMS) {
-        const double m = (double)stats[2 * sample] / (double)E;
-        double var = (double)stats[2 * sample + 1] / (double)E - m * m;
+    if constexpr (SUMS) {  // 2^-24 fixed-point 64-bit sums (gt_epilogue)
+        const long long* fx = reinterpret_cast<const long long*>(stats);
+        const double m = (double)fx[2 * sample] * (1.0 / 16777216.0) / (double)E;
+        double var = (double)fx[2 * sample + 1] * (1.0 / 16777216.0) / (double)E - m * m;
         if (var < 0.0) var = 0.0;
         mu = (float)m;
         rs = (float)(1.0 / sqrt(var + (double)eps));

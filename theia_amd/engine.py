@@ -795,7 +795,7 @@ class StudentEngine:
                 continue
             s0, s1, s2 = hm.sizes
             chw_ws = self.ws(N.lib().theia_layernorm_chw_workspace_bytes(b, s2 * s2 * C) // 4, dev)
-            sums = torch.zeros(3, b, 2, dtype=torch.float32, device=dev)  # LayerNorm statistics out of the convolutions' epilogues
+            sums = torch.zeros(3, b, 2, dtype=torch.int64, device=dev)  # LayerNorm statistics out of the convolutions' epilogues (fixed point)
             u1 = torch.empty(b, 256 * C, dtype=T, device=dev)
             self._conv_fwd(z, pf + "pad.wf", hm.pad["1"].bias, self._plan("pad"), b, u1, relu=False, sums=sums[0])
             v1, st0 = ops.layernorm_chw_fwd(u1, oc[pf + "ln0.g"], oc[pf + "ln0.b"], LN_EPS_HEAD, chw_ws, sums=sums[0])

@@ -142,7 +142,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int
     g.rowtab, g.rowtab_period = N.ptr(rowtab), rowtab_period
     g.M, g.N, g.K, g.ldw, g.ldo, g.act = M, Nn, K, ldw, ldo, act
     g.map = rmap
-    g.ln_sums = N.ptr(ln_sums)  # f32 [images, 2], zeroed by the caller: += (sum, sum of squares) of each image's stored outputs
+    g.ln_sums = N.ptr(ln_sums)  # int64 [images, 2] (2^-24 fixed point), zeroed by the caller: += (sum, sum of squares) per image
+    assert ln_sums is None or ln_sums.dtype == torch.int64
     if a.dtype == torch.float8_e4m3fn:  # fp8 operands (quantize_fp8), bf16 output: de-quantisation factors as device scalars
         assert w.dtype == torch.float8_e4m3fn and out.dtype == torch.bfloat16
         if scale_inv is not None:
@@ -452,7 +453,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dresid, dgamma, dbeta, accumulate: b
 
 def layernorm_chw_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, ws: Optional[torch.Tensor] = None,
                       sums: Optional[torch.Tensor] = None):
-    """x [b, E] (NHWC flattened); gamma/beta f32 [E] in NHWC order.  sums: f32 [b, 2] per-sample (sum, sum of squares) of x already
+    """x [b, E] (NHWC flattened); gamma/beta f32 [E] in NHWC order.  sums: int64 [b, 2] fixed-point per-sample (sum, sum of squares) of x already
     accumulated by the producing GEMM's epilogue (gemm_nt(..., ln_sums=)) -> one pass instead of three."""
     b, E = x.shape
     y = torch.empty_like(x)
