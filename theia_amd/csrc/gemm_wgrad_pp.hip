@@ -77,21 +77,24 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
         st_ry[i] = rem / mp.rows_w;
         st_rx[i] = rem - st_ry[i] * mp.rows_w;
     }
-    // Fast row stepping (wave-uniform choice): when 32 rows are a whole number of images (plain matrices: R = 1) or of image rows
-    // (rows_w divides 32 and 32 / rows_w <= rows_h: the 16x16 maps of the 3x3 convolutions), the two source addresses of a staged
-    // row advance by constants, plus one constant when the row index wraps into the next image -- ~20 VALU instructions per
-    // staged row instead of ~70 for the general decode below (PMC, round 1: 5.8 VALU instructions per MFMA in this kernel,
-    // issued between the MFMAs of the M segment; 3.6x the NT kernel's).
+    // Incremental row stepping (FAST instantiation, chosen by the host): a staged row advances by 32 GEMM rows per half-step,
+    // i.e. by (32 / rows_w) image rows and (32 % rows_w) pixels, with at most one pixel wrap and one image wrap per step
+    // (32 / rows_w + 1 <= rows_h), or by 32 / R whole images for plain matrices (R = 1).  Both source addresses therefore
+    // move by a constant plus one constant per wrap -- ~25 VALU instructions per staged row instead of ~70 for the general
+    // decode below (PMC, round 1: 5.8 VALU instructions per MFMA in this kernel, issued between the MFMAs of the M segment;
+    // 3.6x the NT kernel's).
     const int R_img = mp.rows_h * mp.rows_w;
     const bool whole_images = (MS % R_img) == 0;
-    constexpr bool fast = FAST;  // host: whole_images || (32 % rows_w == 0 && 32 / rows_w <= rows_h)
-    const int RS = whole_images ? 0 : MS / mp.rows_w;  // image rows per step
-    const int64_t oy_step = whole_images ? (int64_t)(MS / R_img) * mp.out_batch_stride : (int64_t)RS * mp.out_sy * mp.out_w * p.ldo;
-    const int64_t ox_step = whole_images ? (int64_t)(MS / R_img) * mp.in_batch_stride : (int64_t)RS * mp.in_sy * mp.in_w * mp.in_c;
-    const int64_t oy_wrap = mp.out_batch_stride - (int64_t)mp.rows_h * mp.out_sy * mp.out_w * p.ldo;  // extra step when ry wraps
-    const int64_t ox_wrap = mp.in_batch_stride - (int64_t)mp.rows_h * mp.in_sy * mp.in_w * mp.in_c;
-    uint64_t f_py[2], f_px[2];   // element addresses of the row's dY / activation piece (valid or not)
-    bool f_xok[2];               // the tap's column is inside the image (constant per staged row)
+    constexpr bool fast = FAST;
+    const int q32 = whole_images ? 0 : MS / mp.rows_w, r32 = whole_images ? 0 : MS % mp.rows_w;  // image rows / pixels per step
+    // element steps of the dY (output side) and activation (input side) addresses: per step, per pixel wrap, per image wrap
+    const int64_t oy_row = (int64_t)mp.out_sy * mp.out_w * p.ldo, oy_pix = (int64_t)mp.out_sx * p.ldo;
+    const int64_t ox_row = (int64_t)mp.in_sy * mp.in_w * mp.in_c, ox_pix = (int64_t)mp.in_sx * mp.in_c;
+    const int64_t oy_step = whole_images ? (int64_t)(MS / R_img) * mp.out_batch_stride : q32 * oy_row + r32 * oy_pix;
+    const int64_t ox_step = whole_images ? (int64_t)(MS / R_img) * mp.in_batch_stride : q32 * ox_row + r32 * ox_pix;
+    const int64_t oy_wx = oy_row - mp.rows_w * oy_pix, ox_wx = ox_row - mp.rows_w * ox_pix;                       // rx wrapped: one row down
+    const int64_t oy_wy = mp.out_batch_stride - mp.rows_h * oy_row, ox_wy = mp.in_batch_stride - mp.rows_h * ox_row;  // ry wrapped: next image
+    uint64_t f_py[2], f_px[2];   // addresses of the row's dY / activation piece (valid or not)
     if constexpr (fast) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -101,7 +104,6 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
             const int64_t ox = (int64_t)st_img[i] * mp.in_batch_stride + mp.in_offset + (int64_t)(iy * mp.in_w + ix) * mp.in_c + c0 + col;
             f_py[i] = reinterpret_cast<uint64_t>(DY + oy);
             f_px[i] = reinterpret_cast<uint64_t>(A + ox);
-            f_xok[i] = (ix >= 0) & (ix < mp.in_w);
         }
     }
     // issue the dY piece and the activation piece of row i for the current half-step, then advance the row by 32
@@ -109,8 +111,8 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
         const bool mok = st_m[i] < m_limit;
         uint64_t sy, sx;
         if constexpr (fast) {
-            const int iy = st_ry[i] * mp.in_sy + dy;
-            const bool xok = mok & f_xok[i] & (iy >= 0) & (iy < mp.in_h);
+            const int iy = st_ry[i] * mp.in_sy + dy, ix = st_rx[i] * mp.in_sx + dx;
+            const bool xok = mok & ((unsigned)iy < (unsigned)mp.in_h) & ((unsigned)ix < (unsigned)mp.in_w);
             sy = (mok & n_ok) ? f_py[i] : zp;
             sx = xok ? f_px[i] : zp;
         } else {
@@ -127,12 +129,17 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sy, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx, (__attribute__((address_space(3))) void*)(dst + PART), 16, 0, 0);
         st_m[i] += MS;
-        if constexpr (fast) {  // constants per step; one more constant when the image row index wraps
-            int ry = st_ry[i] + RS;
-            const bool wrap = ry >= mp.rows_h;  // never true for whole_images (RS = 0, ry stays 0)
-            st_ry[i] = wrap ? ry - mp.rows_h : ry;
-            f_py[i] += (uint64_t)(oy_step + (wrap ? oy_wrap : 0)) * sizeof(bf16_t);
-            f_px[i] += (uint64_t)(ox_step + (wrap ? ox_wrap : 0)) * sizeof(bf16_t);
+        if constexpr (fast) {  // constants per step; one more per wrap (never for whole_images: q32 = r32 = 0, R = 1 keeps rx = ry = 0)
+            int rx = st_rx[i] + r32;
+            const bool wx = rx >= mp.rows_w;
+            rx = wx ? rx - mp.rows_w : rx;
+            int ry = st_ry[i] + q32 + (wx ? 1 : 0);
+            const bool wy = ry >= mp.rows_h;
+            ry = wy ? ry - mp.rows_h : ry;
+            st_rx[i] = rx;
+            st_ry[i] = ry;
+            f_py[i] += (uint64_t)(oy_step + (wx ? oy_wx : 0) + (wy ? oy_wy : 0)) * sizeof(bf16_t);
+            f_px[i] += (uint64_t)(ox_step + (wx ? ox_wx : 0) + (wy ? ox_wy : 0)) * sizeof(bf16_t);
             return;
         }
         // general advance: m += 32  ->  (rx, ry, img) with float-reciprocal wraps (operands < 2^12, one correction each)
@@ -271,7 +278,7 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
         allow_fast = (e != nullptr && strcmp(e, "general") == 0) ? 0 : 1;
     }
     const int R_img = a->map.rows_h * a->map.rows_w;
-    const bool fast = allow_fast && ((32 % R_img) == 0 || ((32 % a->map.rows_w) == 0 && 32 / a->map.rows_w <= a->map.rows_h));
+    const bool fast = allow_fast && ((32 % R_img) == 0 || 32 / a->map.rows_w + 1 <= a->map.rows_h);
     if (fast) hipLaunchKernelGGL(gemm_wgrad_pp_kernel<true>, dim3(tiles * a->splits), dim3(512), lds, stream, *a);
     else hipLaunchKernelGGL(gemm_wgrad_pp_kernel<false>, dim3(tiles * a->splits), dim3(512), lds, stream, *a);
     THEIA_CHECK_LAUNCH("theia_gemm_wgrad(pp)");
