@@ -128,8 +128,7 @@ int theia_gemm_nt(const theia_gemm_args_t* args, int dtype, void* stream);
 /* tile the launcher picks for an (M, N) problem when args->tile == 0: BM*1000 + BN (128128, 128064 or 256256) */
 int theia_gemm_nt_tile(int M, int N, int dtype);
 /* the kernel theia_gemm_nt would run for these arguments (no launch): 128128 / 128064 / 256000 (2-stage kernel, that tile),
- * 256256 (ping-pong), 256009 (ping-pong, 3x3 convolution with one image per tile), 256128 (ping-pong for the rows that fill
- * whole rounds of 256 workgroups + 2-stage 128x128 kernel for the tail rows); negative on a refused request */
+ * 256256 (ping-pong), 256009 (ping-pong, 3x3 convolution with one image per tile); negative on a refused request */
 int theia_gemm_nt_plan(const theia_gemm_args_t* args, int dtype);
 
 /*

@@ -275,30 +275,6 @@ extern "C" int theia_gemm_nt_tile(int M, int N, int dtype) {
     return big ? 256256 : 128128;
 }
 
-// Tail split.  A grid of 256x256 tiles that is a little more than a whole number of rounds of 256 CUs (M = 25216, N = 768: 297
-// tiles) leaves most of the chip idle for a full tile time.  When the last round would be less than 3/8 full and the split lands
-// on an image boundary of the row map, the rows of the whole rounds go to the ping-pong kernel and the remaining rows to the
-// 2-stage 128x128 kernel (twice as many, quarter-size workgroups: one short round).  Returns the number of tail rows (0 = no split).
-static int gemm_nt_tail_rows(const theia_gemm_args_t* a) {
-    static int enabled = -1;
-    if (enabled < 0) {
-        const char* e = getenv("THEIA_GEMM_TAIL");
-        enabled = (e != nullptr && strcmp(e, "off") == 0) ? 0 : 1;
-    }
-    if (!enabled || a->ln_sums != nullptr) return 0;
-    const int tiles_m = cdiv_i(a->M, 256), tiles_n = cdiv_i(a->N, 256);
-    const long T = (long)tiles_m * tiles_n;
-    const int r = (int)(T % 256);
-    if (T <= 256 || T > 4 * 256 || r == 0 || r > 96) return 0;
-    const int rounds = (int)(T / 256);
-    const int m_tiles_head = rounds * 256 / tiles_n;  // m-tiles whose tiles fill (almost) whole rounds
-    const int64_t head = (int64_t)m_tiles_head * 256;
-    const int R = a->map.rows_h * a->map.rows_w;
-    if (head <= 0 || head >= a->M || head % R != 0) return 0;
-    if (a->rowtab != nullptr && head % a->rowtab_period != 0) return 0;
-    return (int)(a->M - head);
-}
-
 // Which kernel theia_gemm_nt runs for these arguments: 128128 / 128064 = 2-stage kernel with that tile, 256000 = 2-stage kernel
 // with the 256x256 tile (problems the ping-pong kernels do not take), 256256 = ping-pong kernel, 256009 = ping-pong kernel for
 // 3x3 convolutions with one image per tile (gemm_conv_pp.hip); negative = error.
@@ -338,7 +314,6 @@ static int gemm_nt_plan(const theia_gemm_args_t* a, int dtype) {
     if (a->tile == 256256) return 256256;
     if (tile == 256256) {
         if (use_pp && use_conv && conv_ok) return 256009;
-        if (use_pp && pp_ok && dtype == THEIA_BF16 && gemm_nt_tail_rows(a) > 0) return 256128;
         return use_pp && pp_ok ? 256256 : 256000;
     }
     return tile;
@@ -373,18 +348,6 @@ extern "C" int theia_gemm_nt(const theia_gemm_args_t* a, int dtype, void* stream
     if (plan < 0) return plan;
     if (plan == 256009) return theia_gemm_conv_pp_launch(a, dtype, s);
     if (plan == 256256) return theia_gemm_nt_pp_launch(a, dtype, s);
-    if (plan == 256128) {  // head rows: ping-pong kernel; tail rows (whole images of the row map): 128x128 kernel
-        const int tail = gemm_nt_tail_rows(a);
-        theia_gemm_args_t h = *a, t = *a;
-        h.M = a->M - tail;
-        const int64_t imgs = (int64_t)h.M / (a->map.rows_h * a->map.rows_w);
-        t.M = tail;
-        t.map.in_offset += imgs * a->map.in_batch_stride;    // every per-row address (A, out, resid, aux) derives from the row map
-        t.map.out_offset += imgs * a->map.out_batch_stride;
-        rc = theia_gemm_nt_pp_launch(&h, dtype, s);
-        if (rc) return rc;
-        return launch_gemm_nt<bf16_t, 128, 128, 2, 2>(&t, s);
-    }
     if (dtype == THEIA_BF16) {
         if (plan == 256000) return launch_gemm_nt<bf16_t, 256, 256, 2, 4>(a, s);
         return plan == 128064 ? launch_gemm_nt<bf16_t, 128, 64, 2, 2>(a, s) : launch_gemm_nt<bf16_t, 128, 128, 2, 2>(a, s);

@@ -126,8 +126,7 @@ GEMM_PROFILE: Optional[list] = None
 WGRAD_PROFILE: Optional[list] = None  # same for theia_gemm_wgrad launches
 
 
-KERNEL_NAMES = {128128: "128x128", 128064: "128x64", 256000: "256x256-2stage", 256256: "256x256", 256009: "256x256-conv",
-                256128: "256x256"}  # 256128: ping-pong kernel + a 128x128 launch for the tail rows (same dominant kernel)
+KERNEL_NAMES = {128128: "128x128", 128064: "128x64", 256000: "256x256-2stage", 256256: "256x256", 256009: "256x256-conv"}
 
 
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int, K: int, rmap: RowMap, ldw: int, ldo: int,
