@@ -29,13 +29,28 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert lib.theia_dtype_size(N.F32) == 4 and lib.theia_dtype_size(N.BF16) == 2 and lib.theia_dtype_size(7) == -1
 
 
-def test_struct_layout_matches_header():
+def test_struct_layout_matches_header(tmp_path):
+    """The ctypes mirrors against the C compiler's layout of include/theia_hip.h (sizeof + offsets of the fields the kernels' callers
+    set last, which move whenever anything before them does)."""
+    import subprocess
     from theia_amd import _native as N
-    # theia_rowmap_t: 1 + 27 + 2 + 2 + 2 + 1 + 5 int32 = 40 int32 (160 B) then 4 int64
+    probes = [("theia_rowmap_t", N.RowMap, "in_batch_stride"), ("theia_gemm_args_t", N.GemmArgs, "tile"),
+              ("theia_gemm_args_t", N.GemmArgs, "w_scale_inv"), ("theia_wgrad_args_t", N.WgradArgs, "defer_bias_reduce"),
+              ("theia_cast_job_t", N.CastJob, "first_block")]
+    src = "#include <stdio.h>\n#include <stddef.h>\n#include \"theia_hip.h\"\nint main(void){\n"
+    for cname, _, field in probes:
+        src += f'printf("%zu %zu\\n", sizeof({cname}), offsetof({cname}, {field}));\n'
+    src += "return 0;}\n"
+    (tmp_path / "p.c").write_text(src)
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(tmp_path / "p.c"), "-o", str(tmp_path / "p")], check=True)
+    rows = subprocess.run([str(tmp_path / "p")], check=True, capture_output=True, text=True).stdout.split("\n")
+    for (cname, ct, field), row in zip(probes, rows):
+        size, off = map(int, row.split())
+        assert C.sizeof(ct) == size, cname
+        assert getattr(ct, field).offset == off, f"{cname}.{field}"
+    # theia_rowmap_t: 40 int32 then 4 int64; theia_gemm_args_t: 8 pointers, 7 int32 + pad, map, tile + reserved, 3 pointers
     assert C.sizeof(N.RowMap) == 160 + 32
-    assert N.RowMap.in_batch_stride.offset == 160
-    assert C.sizeof(N.GemmArgs) == 8 * 8 + 4 * 7 + 4 + C.sizeof(N.RowMap) + 8  # 8 pointers, 7 int32 + pad, map, tile + reserved
-    assert N.GemmArgs.tile.offset == 8 * 8 + 4 * 7 + 4 + C.sizeof(N.RowMap)
+    assert C.sizeof(N.GemmArgs) == 8 * 8 + 4 * 7 + 4 + C.sizeof(N.RowMap) + 8 + 3 * 8
 
 
 def test_host_side_planning_functions():
