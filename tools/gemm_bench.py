@@ -20,6 +20,7 @@ SHAPES = {  # name: (M, N, K, kind)
     "fc2": (25216, 768, 3072, "plain"),
     "proj": (25216, 768, 768, "plain"),
     "qkv": (25216, 2304, 768, "plain"),
+    "qkvd": (25216, 768, 2304, "plain"),
     "up64c": (131072, 768, 3072, "plain"),
 }
 
