@@ -21,6 +21,7 @@
 //           behind weight tile u + 1 -> the two pieces of weight tile u + 1 have landed (tiles u + 2 .. u + 5 stay in flight),
 //           then the barrier makes every wave's pieces visible.  Image slice s + 1 sits in the queue right behind weight
 //           tile 9 s + 7; the vmcnt(8) at the end of R(9 s + 7) retires it, two units before its first read in R(9 s + 9).
+#include <type_traits>
 #include "gemm_tile.h"
 
 __device__ uint4 g_cv_zero_page[16];  // 256 B of zeros: source of out-of-range rows (never advanced)
@@ -213,7 +214,10 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
     asm volatile("" ::: "memory");
 
     float* ep = reinterpret_cast<float*>(smem) + wave * (64 * (WN + 4));
-    gt_epilogue<T, WM, WN, SUMS>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
+    const bool prefetch = sizeof(T) == 2 && (p.resid != nullptr || p.act == THEIA_ACT_MUL_DGELU || p.act == THEIA_ACT_MUL_DRELU);
+    if constexpr (SUMS) gt_epilogue<T, WM, WN, true, false, 4, -1>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);  // see gemm_pp.hip
+    else if (prefetch) gt_epilogue<T, WM, WN, false, false, 4, 1>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
+    else gt_epilogue<T, WM, WN, false, false, 4, 0>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
 // Does the row map describe a convolution this kernel takes?  (one 16x16 output image per 256-row tile, stride 1, taps a

@@ -18,6 +18,7 @@
 //        (interval 2h-2) and of group 1 (interval 2h-1), both closed by s_waitcnt lgkmcnt(0) before their barrier.
 //   RAW  half-tile h+1 is first read in interval 2h+2 (group 0, R(h+1)); every wave has waited for its own pieces of it at
 //        the end of its R(h) (interval 2h / 2h+1), i.e. before barrier 2h+2.
+#include <type_traits>
 #include "gemm_tile.h"
 
 // zeros read by out-of-range rows / taps: such a lane's source pointer is the page start and advances with the k offset
@@ -273,8 +274,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
 
     PP_PHASE(4)
     float* ep = reinterpret_cast<float*>(smem) + wave * (64 * (WN + 4));
-    if constexpr (sizeof(T) == 1) gt_epilogue<bf16_t, WM, WN, SUMS, true>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);  // fp8 operands, bf16 out
-    else gt_epilogue<T, WM, WN, SUMS>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
+    using OutT = typename std::conditional<sizeof(T) == 1, bf16_t, T>::type;  // fp8 operands: bf16 out, accumulators rescaled
+    const bool prefetch = sizeof(OutT) == 2 && (p.resid != nullptr || p.act == THEIA_ACT_MUL_DGELU || p.act == THEIA_ACT_MUL_DRELU);
+    // (the statistics-emitting instantiation keeps ONE epilogue that decides at run time: with two the register allocation of its
+    // main loop spills -- the stride-2 transposed convolutions ran 2x slower)
+    if constexpr (SUMS) gt_epilogue<OutT, WM, WN, true, sizeof(T) == 1, 4, -1>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
+    else if (prefetch) gt_epilogue<OutT, WM, WN, false, sizeof(T) == 1, 4, 1>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
+    else gt_epilogue<OutT, WM, WN, false, sizeof(T) == 1, 4, 0>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
     PP_PHASE(5)
 #ifdef PP_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -104,6 +104,15 @@ template <typename T> __device__ __forceinline__ float gt_gelu_grad(float x) {
     }
 }
 
+// cycle stamps of block 0's epilogue for tools/pp_trace.hip (-DPP_TRACE); compiled out of the library
+#ifdef PP_TRACE
+__device__ unsigned long long g_ep_trace[8][16];
+#define GT_EP_STAMP(k) \
+    if (blockIdx.x == 0 && lane == 0) g_ep_trace[threadIdx.x >> 6][k] = __builtin_readcyclecounter();
+#else
+#define GT_EP_STAMP(k)
+#endif
+
 // Epilogue of one wave's WM x WN accumulator tile.  acc[i][j] is the 16x16 fragment for n-frag i / m-frag j produced
 // with the WEIGHT fragment as the MFMA A operand (lane: m = j*16 + lane&15, n = i*16 + (lane>>4)*4 .. +4).
 // The tile goes through a wave-private LDS region (EPH rows at a time) and is re-read row-contiguously so that every
@@ -114,7 +123,10 @@ template <typename T> __device__ __forceinline__ float gt_gelu_grad(float x) {
 // SUMS: also accumulate p.ln_sums (a separate instantiation, launched only for the GEMMs that feed a whole-sample LayerNorm, so
 // that every other launch pays nothing for it)
 // SCALE: multiply the accumulators by (*p.a_scale_inv) * (*p.w_scale_inv) first (fp8 operands: T is then the OUTPUT type, bf16)
-template <typename T, int WM, int WN, bool SUMS = false, bool SCALE = false, int GPMAX = 4>
+// PREF: 1 = the launch has a residual / aux_in row to prefetch (bf16), 0 = it has not (callers branch once, wave-uniformly, between
+// the two instantiations: without a prefetch the loop carries no vector-memory wait and no prefetch registers), -1 = decide at
+// run time inside whether to prefetch and wait at the end of every group regardless (the smaller kernels)
+template <typename T, int WM, int WN, bool SUMS = false, bool SCALE = false, int GPMAX = 4, int PREF = -1>
 __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], float* ep /* wave-private LDS */,
                                             const theia_gemm_args_t& p, int m_wave0, int n_wave0, int lane) {
     constexpr int FM = WM / 16, FN = WN / 16;
@@ -142,16 +154,49 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
     if constexpr (SCALE) alpha = (p.a_scale_inv != nullptr ? *p.a_scale_inv : 1.0f) * (p.w_scale_inv != nullptr ? *p.w_scale_inv : 1.0f);
     const bool want_aux = act == THEIA_ACT_MUL_DGELU || act == THEIA_ACT_MUL_DRELU;
     const T* __restrict__ PRE = want_aux ? AUXI : RES;  // the row that is prefetched (bf16 path)
-    const bool pre_on = sizeof(T) == 2 && PRE != nullptr;
-    // output element offset of GEMM row m (column n), and whether this lane has anything to do there
-    auto row_offset = [&](int m, bool& live) -> int64_t {
-        live = (m < p.M) && n_ok;
-        const int mm = live ? m : 0;
-        int rem, rx;
-        const int img = gt_divmod(mm, R, rcp_R, rem);
-        const int ry = gt_divmod(rem, mp.rows_w, rcp_w, rx);
+    const bool pre_on = PREF == 0 ? false : (sizeof(T) == 2 && PRE != nullptr);
+    // Output element offset of this lane's row in every pass.  The epilogue is bound by VALU issue (a wave64 instruction holds the
+    // SIMD for 4 cycles and two waves share it: ~700 cycles per pass when decoding each row with two divisions and 64-bit
+    // products, tools/pp_trace.hip), so the row (image, y, x) is decoded ONCE and then stepped by the RPP rows between passes:
+    //   plain maps (one row per "image"):  offset += RPP * out_batch_stride
+    //   image maps whose step wraps at most once in x and once in y (RPP / rows_w + 1 <= rows_h):  offset += d_step, + d_wx when
+    //   x leaves the row, + d_wy when y leaves the image
+    //   anything else: decode again.
+    auto decode_row = [&](int m, int& ry, int& rx) -> int64_t {
+        int rem;
+        const int img = gt_divmod(m, R, rcp_R, rem);
+        ry = gt_divmod(rem, mp.rows_w, rcp_w, rx);
         return (int64_t)img * mp.out_batch_stride + mp.out_offset +
-               (int64_t)((ry * mp.out_sy + mp.out_y0) * mp.out_w + rx * mp.out_sx + mp.out_x0) * p.ldo + (live ? n : 0);
+               (int64_t)((ry * mp.out_sy + mp.out_y0) * mp.out_w + rx * mp.out_sx + mp.out_x0) * p.ldo;
+    };
+    const int step_qw = RPP / mp.rows_w, step_rw = RPP - step_qw * mp.rows_w;  // wave-uniform
+    const int step_mode = R == 1 ? 0 : (step_qw + 1 <= mp.rows_h ? 1 : 2);
+    const int64_t row_pitch = (int64_t)mp.out_sy * mp.out_w * p.ldo;             // offset of one map row down
+    const int64_t d_step = step_mode == 0 ? (int64_t)RPP * mp.out_batch_stride : step_qw * row_pitch + (int64_t)step_rw * mp.out_sx * p.ldo;
+    const int64_t d_wx = row_pitch - (int64_t)mp.rows_w * mp.out_sx * p.ldo;
+    const int64_t d_wy = mp.out_batch_stride - mp.rows_h * row_pitch;
+    int dead_ry, dead_rx;
+    const int64_t off_dead = decode_row(0, dead_ry, dead_rx);  // where dead lanes (rows >= M, columns >= N) prefetch from: row 0, column 0
+    int m_cur = m_wave0 + lrow, cur_ry, cur_rx;
+    int64_t off_cur = decode_row(m_cur, cur_ry, cur_rx) + n;
+    auto next_row = [&]() {  // advance this lane's row by RPP
+        m_cur += RPP;
+        if (step_mode == 2) {
+            off_cur = decode_row(m_cur, cur_ry, cur_rx) + n;
+            return;
+        }
+        off_cur += d_step;
+        if (step_mode == 1) {
+            cur_rx += step_rw;
+            cur_ry += step_qw;
+            const bool wx = cur_rx >= mp.rows_w;
+            cur_rx -= wx ? mp.rows_w : 0;
+            cur_ry += wx ? 1 : 0;
+            off_cur += wx ? d_wx : 0;
+            const bool wy = cur_ry >= mp.rows_h;
+            cur_ry -= wy ? mp.rows_h : 0;
+            off_cur += wy ? d_wy : 0;
+        }
     };
     auto unpack8 = [](const gt_u32x4& u, float (&f)[8]) {
         const uint32_t w4[4] = {u[0], u[1], u[2], u[3]};
@@ -168,7 +213,7 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
     constexpr int GP = NPS < GPMAX ? NPS : GPMAX;      // passes per group (unrolled: static registers for the prefetched rows)
     constexpr int NG = WM / RPP / GP;          // groups per wave tile
     constexpr int GPH = NPS / GP;              // groups per LDS half
-    static_assert(GP == 4 || GP == 2, "explicit waits below are written for 2 or 4 passes per group");
+    static_assert(GP == 8 || GP == 4 || GP == 2, "explicit waits below are written for 2, 4 or 8 passes per group");
     bool nlive[GP];
     int64_t noff[GP];
     gt_u32x4 npre[GP];
@@ -186,19 +231,37 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
     auto fetch_group = [&](int g) {
 #pragma unroll
         for (int q = 0; q < GP; ++q) {
-            noff[q] = row_offset(m_wave0 + lrow + (g * GP + q) * RPP, nlive[q]);
+            nlive[q] = (m_cur < p.M) && n_ok;
+            noff[q] = nlive[q] ? off_cur : off_dead;
+            next_row();
             npre[q] = (gt_u32x4){0u, 0u, 0u, 0u};
-            if (pre_on)  // wave-uniform; dead lanes read row 0 (valid memory)
+            if (PREF == 1 || pre_on)  // wave-uniform; dead lanes read row 0 (valid memory)
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(npre[q]) : "v"(PRE + noff[q]) : "memory");
         }
     };
+    // wait until at most N vector-memory operations are outstanding, tied to the prefetch registers
+#define GT_WAIT_PRE(N)                                                                                                                            \
+    do {                                                                                                                                          \
+        if constexpr (GP == 8)                                                                                                                    \
+            asm volatile("s_waitcnt vmcnt(%8)"                                                                                                    \
+                         : "+v"(npre[0]), "+v"(npre[1]), "+v"(npre[2]), "+v"(npre[3]), "+v"(npre[GP - 4]), "+v"(npre[GP - 3]), "+v"(npre[GP - 2]), \
+                           "+v"(npre[GP - 1])                                                                                                     \
+                         : "n"(N)                                                                                                                 \
+                         : "memory");                                                                                                             \
+        else if constexpr (GP == 4)                                                                                                               \
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(npre[0]), "+v"(npre[1]), "+v"(npre[2]), "+v"(npre[3]) : "n"(N) : "memory");                 \
+        else                                                                                                                                      \
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(npre[0]), "+v"(npre[1]) : "n"(N) : "memory");                                               \
+    } while (0)
+    GT_EP_STAMP(0)
     fetch_group(0);
-    if constexpr (GP == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(npre[0]), "+v"(npre[1]), "+v"(npre[2]), "+v"(npre[3])::"memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(npre[0]), "+v"(npre[1])::"memory");
+    if constexpr (PREF != 0) GT_WAIT_PRE(0);
     __builtin_amdgcn_s_waitcnt(0x0f70);  // the same vmcnt(0), visible to the compiler: the bias row has landed too
     T* const dump = reinterpret_cast<T*>(g_gt_dump) + lane * 8;
+    GT_EP_STAMP(1)
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
+        GT_EP_STAMP(2 + 3 * (g & 3))
         if (g % GPH == 0) {
             // accumulators of the next EPH rows -> wave-private LDS tile (static register indices: one copy per half,
             // selected by a wave-uniform branch)
@@ -218,6 +281,7 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
             __builtin_amdgcn_wave_barrier();
         }
+        GT_EP_STAMP(3 + 3 * (g & 3))
         bool live[GP];
         int64_t off[GP];
         gt_u32x4 pre[GP];
@@ -290,10 +354,13 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
                 lq1 += first ? 0.f : sq;
             }
         }
-        // group g+1's rows have landed once at most the GP (or more) stores issued after them are outstanding
-        if constexpr (GP == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(npre[0]), "+v"(npre[1]), "+v"(npre[2]), "+v"(npre[3])::"memory");
-        else asm volatile("s_waitcnt vmcnt(2)" : "+v"(npre[0]), "+v"(npre[1])::"memory");
+        // group g+1's rows have landed once at most the GP (or more) stores issued after them are outstanding.  Without a
+        // prefetch there is nothing to wait for: the stores of all groups stream out back to back (a wait here would hold every
+        // group until the previous group's stores are ACKNOWLEDGED, ~4k cycles each when all CUs are in their epilogues at once)
+        GT_EP_STAMP(4 + 3 * (g & 3))
+        if constexpr (PREF != 0) GT_WAIT_PRE(GP);
     }
+    GT_EP_STAMP(14)
     if constexpr (SUMS) {
         ls0 = wave_sum(ls0);
         lq0 = wave_sum(lq0);

@@ -46,6 +46,14 @@ int main(int argc, char** argv) {
         }
         printf("\n");
     }
+    unsigned long long et[8][16];
+    hipMemcpyFromSymbol(et, HIP_SYMBOL(g_ep_trace), sizeof(et));
+    printf("epilogue of block 0 (entry, bias/prefetch landed, then per group: start, staged, passes issued; end), cycles since the wave's entry\n");
+    for (int wv = 0; wv < 8; wv += 4) {
+        printf("wave %d:", wv);
+        for (int k = 1; k < 15; ++k) printf(" %6lld", (long long)(et[wv][k] - et[wv][0]));
+        printf("\n");
+    }
     unsigned long long ph[2][8][7];
     hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_pp_phase), sizeof(ph));
     printf("phases (entry, addr setup done, prologue issued, loop start, loop end, epilogue issued, stores acknowledged), cycles since entry of block 0 wave 0\n");
