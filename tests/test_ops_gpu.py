@@ -570,6 +570,28 @@ def test_cast_batch_matches_single_casts(dt):
     got["b"], ref["b"] = torch.empty(77, dtype=torch.float32, device=dev), torch.empty(77, dtype=torch.float32, device=dev)
     cb.add_cast(bias, got["b"])
     ops.cast(bias, ref["b"])
+    # ragged / unaligned shapes (scalar paths), a j-fast transpose whose last float4 is partial, and the real operand sizes
+    wr = h((37, 50), 46).to(dev)
+    got["rT"], ref["rT"] = torch.zeros(50, 37, dtype=dt, device=dev), torch.zeros(50, 37, dtype=dt, device=dev)
+    cb.add_transpose(wr, got["rT"])
+    ops.cast_transpose(wr, ref["rT"])
+    wp = h((64, 70), 47).to(dev)
+    got["pT"], ref["pT"] = torch.zeros(70, 64, dtype=dt, device=dev), torch.zeros(70, 64, dtype=dt, device=dev)
+    cb.add_transpose(wp, got["pT"])
+    ops.cast_transpose(wp, ref["pT"])
+    big = h((768, 3072), 48).to(dev)
+    got["bT"], ref["bT"] = torch.empty(3072, 768, dtype=dt, device=dev), torch.empty(3072, 768, dtype=dt, device=dev)
+    cb.add_transpose(big, got["bT"])
+    ops.cast_transpose(big, ref["bT"])
+    cw2 = h((192, 192, 3, 3), 49).to(dev)
+    for name, pack in (("cf2", ops.plan_conv3x3(192, 16).pack_fwd), ("cd2", ops.plan_conv3x3(192, 16).pack_dgrad)):
+        got[name], ref[name] = torch.empty(192, 9 * 192, dtype=dt, device=dev), torch.empty(192, 9 * 192, dtype=dt, device=dev)
+        cb.add(cw2, got[name], *pack)
+        ops.cast_permute3(cw2, ref[name], *pack)
+    g2 = h((64, 31, 31), 50).to(dev)  # [C, H, W] -> [HW, C] with HW = 961 (odd source pitch)
+    got["g2"], ref["g2"] = torch.empty(961 * 64, dtype=torch.float32, device=dev), torch.empty(961 * 64, dtype=torch.float32, device=dev)
+    cb.add(g2, got["g2"], 1, 961, 64, 0, 1, 961)
+    ops.cast_permute3(g2, ref["g2"], 961, 1, 64, 1, 0, 961)
     cb.run()
     for k in got:
         assert torch.equal(got[k], ref[k]), k

@@ -99,9 +99,16 @@ extern "C" int theia_cast_permute3(const float* src, void* dst, int d0, int d1, 
     return THEIA_OK;
 }
 
-// Batched permuting cast: block -> (job, i, T1 x T2 tile of the (j, k) plane), T1*T2 = 4096 elements, 256 threads.
-// s2 == 1 (plain casts): straight 16-byte loads / 8-byte stores, no LDS.  Otherwise the tile goes through LDS so that the
-// source is read along whichever of j / k has the smaller source stride and the destination is written along k.
+// Batched permuting cast: block -> (job, i, T1 x T2 tile of the (j, k) plane), T1*T2 = 4096 elements (both powers of two),
+// 256 threads.  HBM-bound work (4 B read, 2 B written per element), so every path moves 16 bytes per lane where the job's strides
+// allow it and indexes its tile with shifts:
+//   s2 == 1 (plain casts): float4 loads / 8-byte stores, no LDS.
+//   otherwise the tile goes through LDS ([j][k], pitch T2 + 1):
+//     load  a) the tile's (k, j) plane is one contiguous run of the source (s1 == 1, s2 == d1 <= T1: the 3x3 convolution weights
+//              [co][ci][3][3] -> [co][tap][ci]): float4 loads along the run, (k, j) = divmod(index, d1)
+//           b) s1 == 1 (transposes): float4 loads along j
+//           c) anything else: one element per lane along whichever of j / k has the smaller source stride
+//     store 8 consecutive k per lane (16-byte bf16 / 2 x 16-byte f32 stores) when d2, t0, t1 are multiples of 8, else one element.
 template <typename T>
 __global__ __launch_bounds__(256) void cast_batch_kernel(const theia_cast_job_t* __restrict__ jobs, int njobs) {
     __shared__ float tile[4096 + 128];
@@ -116,15 +123,18 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(const theia_cast_job_t*
     const int tk = (int)(r % jb.tiles2);
     r /= jb.tiles2;
     const int tj = (int)(r % jb.tiles1), i = (int)(r / jb.tiles1);
-    const int T1 = jb.tile1, T2 = jb.tile2;          // T1 * T2 == 4096, T2 a multiple of 4
+    const int T1 = jb.tile1, T2 = jb.tile2;          // T1 * T2 == 4096, powers of two, T2 >= 64
+    const int L1 = 31 - __builtin_clz(T1), L2 = 12 - L1;
     const int j0 = tj * T1, k0 = tk * T2;
+    const int tid = threadIdx.x;
     const float* __restrict__ src = jb.src + (int64_t)i * jb.s0;
-    const bool vec = jb.s2 == 1 && (jb.d2 & 3) == 0 && (jb.s1 & 3) == 0 && (jb.s0 & 3) == 0 && (jb.t1 & 3) == 0 && (jb.t0 & 3) == 0 &&
-                     (reinterpret_cast<uint64_t>(jb.src) & 15) == 0 && (reinterpret_cast<uint64_t>(jb.dst) & 15) == 0;
+    const bool src16 = (reinterpret_cast<uint64_t>(jb.src) & 15) == 0 && (jb.s0 & 3) == 0;
+    const bool vec = jb.s2 == 1 && (jb.d2 & 3) == 0 && (jb.s1 & 3) == 0 && src16 && (jb.t1 & 3) == 0 && (jb.t0 & 3) == 0 &&
+                     (reinterpret_cast<uint64_t>(jb.dst) & 15) == 0;
     if (vec) {  // wave-uniform (per job)
-        const int Q2 = T2 >> 2;
-        for (int e = threadIdx.x; e < 1024; e += 256) {
-            const int kq = e % Q2, jj = e / Q2;
+        const int LQ = L2 - 2;
+        for (int e = tid; e < 1024; e += 256) {
+            const int kq = e & ((1 << LQ) - 1), jj = e >> LQ;
             const int j = j0 + jj, k = k0 + kq * 4;
             if (j < jb.d1 && k < jb.d2) {
                 const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)j * jb.s1 + k);
@@ -142,22 +152,87 @@ __global__ __launch_bounds__(256) void cast_batch_kernel(const theia_cast_job_t*
         return;
     }
     const int P2 = T2 + 1;                             // LDS pitch of a j-row
-    if (jb.s1 < jb.s2) {                               // j is the fast source dimension
-        for (int e = threadIdx.x; e < 4096; e += 256) {
-            const int jj = e % T1, kk = e / T1;
+    const int nk = min(T2, jb.d2 - k0);
+    if (jb.s1 == 1 && jb.s2 == jb.d1 && jb.tiles1 == 1) {
+        // a) contiguous run of nk * d1 floats starting at k0 * d1 (16-byte aligned when k0 * d1 is a multiple of 4: T2 >= 64 is)
+        const float* base = src + (int64_t)k0 * jb.d1;
+        const int n = nk * jb.d1;
+        const float rcp = 1.0f / (float)jb.d1;
+        const bool al = src16 && ((k0 * jb.d1) & 3) == 0;
+        for (int e = tid * 4; e < n; e += 1024) {
+            float v[4];
+            if (al && e + 3 < n) {
+                const float4 q = *reinterpret_cast<const float4*>(base + e);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = e + c < n ? base[e + c] : 0.f;
+            }
+            int k = (int)((float)e * rcp), j = e - k * jb.d1;   // e < 2^24: the float quotient is within one of the answer
+            if (j < 0) { --k; j += jb.d1; }
+            if (j >= jb.d1) { ++k; j -= jb.d1; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (e + c < n) tile[j * P2 + k] = v[c];
+                if (++j == jb.d1) { j = 0; ++k; }
+            }
+        }
+    } else if (jb.s1 == 1 && L1 >= 2 && src16 && (jb.s2 & 3) == 0) {
+        // b) float4 along j (j0 is a multiple of T1 >= 4)
+        const int LQ = L1 - 2;
+        for (int e = tid; e < 1024; e += 256) {
+            const int jq = e & ((1 << LQ) - 1), kk = e >> LQ;
+            const int j = j0 + jq * 4, k = k0 + kk;
+            if (k < jb.d2 && j < jb.d1) {
+                const float* q = src + j + (int64_t)k * jb.s2;
+                float* t = tile + (jq * 4) * P2 + kk;
+                if (j + 3 < jb.d1) {
+                    const float4 v = *reinterpret_cast<const float4*>(q);
+                    t[0] = v.x; t[P2] = v.y; t[2 * P2] = v.z; t[3 * P2] = v.w;
+                } else {
+                    for (int c = 0; j + c < jb.d1; ++c) t[c * P2] = q[c];
+                }
+            }
+        }
+    } else if (jb.s1 < jb.s2) {                        // c) j is the fast source dimension
+        for (int e = tid; e < 4096; e += 256) {
+            const int jj = e & (T1 - 1), kk = e >> L1;
             const int j = j0 + jj, k = k0 + kk;
             if (j < jb.d1 && k < jb.d2) tile[jj * P2 + kk] = src[j * jb.s1 + k * jb.s2];
         }
     } else {
-        for (int e = threadIdx.x; e < 4096; e += 256) {
-            const int kk = e % T2, jj = e / T2;
+        for (int e = tid; e < 4096; e += 256) {
+            const int kk = e & (T2 - 1), jj = e >> L2;
             const int j = j0 + jj, k = k0 + kk;
             if (j < jb.d1 && k < jb.d2) tile[jj * P2 + kk] = src[j * jb.s1 + k * jb.s2];
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 4096; e += 256) {
-        const int kk = e % T2, jj = e / T2;
+    const bool to_f32 = jb.dst_f32 || sizeof(T) == 4;
+    const bool wide = (jb.d2 & 7) == 0 && (jb.t0 & 7) == 0 && (jb.t1 & 7) == 0 && (reinterpret_cast<uint64_t>(jb.dst) & 15) == 0;
+    if (wide) {
+        const int LQ = L2 - 3;
+        for (int e = tid; e < 512; e += 256) {
+            const int kq = e & ((1 << LQ) - 1), jj = e >> LQ;
+            const int j = j0 + jj, k = k0 + kq * 8;
+            if (j < jb.d1 && k < jb.d2) {
+                const int64_t o = (int64_t)i * jb.t0 + (int64_t)j * jb.t1 + k;
+                float v[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = tile[jj * P2 + kq * 8 + c];
+                if (to_f32) {
+                    float* d = reinterpret_cast<float*>(jb.dst) + o;
+                    *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    store8(reinterpret_cast<bf16_t*>(jb.dst) + o, v);
+                }
+            }
+        }
+        return;
+    }
+    for (int e = tid; e < 4096; e += 256) {
+        const int kk = e & (T2 - 1), jj = e >> L2;
         const int j = j0 + jj, k = k0 + kk;
         if (j < jb.d1 && k < jb.d2) {
             const int64_t o = (int64_t)i * jb.t0 + (int64_t)j * jb.t1 + k;
