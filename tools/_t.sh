@@ -1,7 +1,8 @@
-cd /root/repo; mkdir -p gpurun_out/r2c; rm -f gpurun_out/r2c/*
-timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -k "cast_batch" 2>&1 | tail -5 > gpurun_out/r2c/tests.log
-timeout 900 python -m pytest tests/test_train_gpu.py tests/test_model_gpu.py -x -q 2>&1 | tail -5 >> gpurun_out/r2c/tests.log
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace -d /tmp/prof -o p -- python /root/repo/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-selfcheck --no-roofline > /root/repo/gpurun_out/r2c/bench.log 2>&1
-DB=$(find /tmp/prof -name "*.db" | head -1)
-python /root/repo/tools/rocpd_stats.py $DB --csv /root/repo/gpurun_out/r2c/stats.csv > /dev/null 2>&1
+cd /root/repo; mkdir -p gpurun_out/r2a; rm -f gpurun_out/r2a/*
+timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -k "attention" 2>&1 | tail -3 > gpurun_out/r2a/tests.log
+for v in old new old new; do
+  cp build/libtheia_hip_$v.so theia_amd/lib/libtheia_hip.so
+  echo "# $v" >> gpurun_out/r2a/attn.txt
+  timeout 120 python tools/attn_bench.py --iters 50 2>&1 | grep -v amdgpu >> gpurun_out/r2a/attn.txt
+done
+cp build/libtheia_hip_new.so theia_amd/lib/libtheia_hip.so
