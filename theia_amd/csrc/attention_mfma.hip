@@ -27,13 +27,35 @@ __device__ __forceinline__ void am_mma(am_f32x4& acc, const uint4& a, const uint
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(am_bf16x8, a), __builtin_bit_cast(am_bf16x8, b), acc, 0, 0, 0);
 }
 
-// stage `rows` token rows (zero beyond n) of a [token][64] bf16 matrix with the given global row stride
-__device__ __forceinline__ void am_stage(const bf16_t* __restrict__ src, int64_t row_stride, int n, int rows, char* __restrict__ dst) {
-    for (int v = threadIdx.x; v < rows * 8; v += blockDim.x) {
-        const int r = v >> 3, c = v & 7;
-        uint4 x = make_uint4(0, 0, 0, 0);
-        if (r < n) x = *reinterpret_cast<const uint4*>(src + r * row_stride + c * 8);
-        *reinterpret_cast<uint4*>(dst + r * AM_PITCH + c * 16) = x;
+// Stage two [token][64] bf16 matrices (ROWS_A / ROWS_B token rows, zero beyond n) with the given global row strides.  All of a
+// thread's 16-byte pieces of BOTH matrices are requested before the first is written to LDS: as a load -> wait -> store loop (what
+// the compiler makes of the obvious form) the staging was 13 exposed memory latencies per workgroup, most of the forward kernel.
+template <int ROWS_A, int ROWS_B, int NT>
+__device__ __forceinline__ void am_stage2(const bf16_t* __restrict__ srcA, int64_t strideA, char* __restrict__ dstA,
+                                          const bf16_t* __restrict__ srcB, int64_t strideB, char* __restrict__ dstB, int n) {
+    constexpr int ITA = (ROWS_A * 8 + NT - 1) / NT, ITB = (ROWS_B * 8 + NT - 1) / NT;
+    uint4 xa[ITA], xb[ITB];
+#pragma unroll
+    for (int it = 0; it < ITA; ++it) {
+        const int v = threadIdx.x + it * NT, r = v >> 3, c = v & 7;
+        xa[it] = make_uint4(0, 0, 0, 0);
+        if (r < n && r < ROWS_A) xa[it] = *reinterpret_cast<const uint4*>(srcA + r * strideA + c * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < ITB; ++it) {
+        const int v = threadIdx.x + it * NT, r = v >> 3, c = v & 7;
+        xb[it] = make_uint4(0, 0, 0, 0);
+        if (r < n && r < ROWS_B) xb[it] = *reinterpret_cast<const uint4*>(srcB + r * strideB + c * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < ITA; ++it) {
+        const int v = threadIdx.x + it * NT, r = v >> 3, c = v & 7;
+        if (r < ROWS_A) *reinterpret_cast<uint4*>(dstA + r * AM_PITCH + c * 16) = xa[it];
+    }
+#pragma unroll
+    for (int it = 0; it < ITB; ++it) {
+        const int v = threadIdx.x + it * NT, r = v >> 3, c = v & 7;
+        if (r < ROWS_B) *reinterpret_cast<uint4*>(dstB + r * AM_PITCH + c * 16) = xb[it];
     }
 }
 
@@ -86,8 +108,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
     const int D = h * 64;
     const int64_t rs = 3 * (int64_t)D;
     const bf16_t* base = qkv + (int64_t)bi * n * rs + hi * 64;
-    am_stage(base + D, rs, n, 208, sK);
-    am_stage(base + 2 * D, rs, n, AM_ROWS, sV);
+    am_stage2<208, AM_ROWS, 256>(base + D, rs, sK, base + 2 * D, rs, sV, n);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q16 = lane & 15, g = lane >> 4;
@@ -162,8 +183,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_kernel(const bf16_t* __r
     const int D = h * 64;
     const int64_t rs = 3 * (int64_t)D;
     const bf16_t* base = qkv + (int64_t)bi * n * rs + hi * 64;
-    am_stage(base + D, rs, n, AM_ROWS, sK);
-    am_stage(base + 2 * D, rs, n, 208, sV);
+    am_stage2<AM_ROWS, 208, 512>(base + D, rs, sK, base + 2 * D, rs, sV, n);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q16 = lane & 15, g = lane >> 4;
@@ -240,12 +260,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_kernel(const bf16_t* __
     const int D = h * 64;
     const int64_t rs = 3 * (int64_t)D;
     const bf16_t* base = qkv + (int64_t)bi * n * rs + hi * 64;
-    am_stage(base, rs, n, AM_ROWS, sQ);
-    am_stage(d_o + (int64_t)bi * n * D + hi * 64, (int64_t)D, n, AM_ROWS, sG);
-    for (int i = threadIdx.x; i < AM_ROWS; i += blockDim.x) {
+    if (threadIdx.x < AM_ROWS) {  // requested ahead of the operand pieces below (one wait for everything)
+        const int i = threadIdx.x;
         sL[i] = i < n ? lse[(int64_t)bh * n + i] * AM_LOG2E : INFINITY;  // log2-domain; +inf beyond n: probability 0
         sD[i] = i < n ? delta[(int64_t)bh * n + i] : 0.f;
     }
+    am_stage2<AM_ROWS, AM_ROWS, 512>(base, rs, sQ, d_o + (int64_t)bi * n * D + hi * 64, (int64_t)D, sG, n);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k16 = lane & 15, g = lane >> 4;
