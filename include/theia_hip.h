@@ -116,7 +116,8 @@ typedef struct theia_gemm_args {
      * depend on arrival order -- (image = GEMM row / (rows_h*rows_w), needs rows_h*rows_w >= 128).  The whole-sample LayerNorm that follows a translator
      * convolution (adapter_heads.py:306-324) takes its statistics from here instead of re-reading the activation; the caller
      * zeroes the buffer before the first launch that writes the tensor (the 4 output-parity launches of a stride-2 transposed
-     * convolution add into the same sums). */
+     * convolution add into the same sums).  Together with resid / aux_in (no layer of the reference needs both) the launch runs
+     * on the 128x128 kernel; tile requests 256256 / 256009 and THEIA_FP8 operands are then THEIA_ERR_UNSUPPORTED. */
     float* ln_sums;
     /* THEIA_FP8: device pointers to the de-quantisation factors 1/scale of the two operands (one f32 each); the accumulator is
      * multiplied by their product before the epilogue.  NULL = 1. */

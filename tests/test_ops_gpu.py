@@ -768,3 +768,32 @@ def test_fp8_implicit_gemm_convolutions(kind):
     for rmap, mpi in plan.fwd:
         ops.gemm_nt(x8, wf8, out, b * mpi, C, rmap.ntaps * C, rmap, 9 * C, C, bias=bias.to(dev), scale_inv=inv)
     assert relerr(out.float(), ref) < TOL[torch.bfloat16]
+
+
+def test_layernorm_statistics_with_a_residual_run_on_the_2stage_kernel():
+    """ln_sums + resid: the ping-pong kernels' statistics instantiations have no residual prefetch, the library routes such a launch
+    to the 128x128 kernel (and refuses an explicit 256x256 request instead of computing something else)."""
+    from theia_amd import ops, _native as Nn
+    dev = _dev()
+    dt, b, C = torch.bfloat16, 64, 768   # 64 images x 256 rows, N = 768: the library's own choice would be the ping-pong kernel
+    x = h((b, 16, 16, C), 81, 1.0)
+    W = h((C, C, 3, 3), 82, 1.0 / math.sqrt(9 * C))
+    res = h((b, 16, 16, C), 83, 1.0)
+    plan = ops.plan_conv3x3(C, 16)
+    (rmap, mpi), = plan.fwd
+    xd, wf, rd = x.to(dev, dt), _pack(plan.pack_fwd, W, dt, dev), res.to(dev, dt)
+    assert Nn.lib().theia_gemm_nt_tile(b * mpi, C, Nn.BF16) == 256256
+    out = torch.zeros(b, 16, 16, C, dtype=dt, device=dev)
+    sums = torch.zeros(b, 2, dtype=torch.int64, device=dev)
+    kw = dict(resid=rd, ln_sums=sums)
+    assert ops.gemm_nt(xd, wf, out, b * mpi, C, 9 * C, rmap, 9 * C, C, plan_only=True, **kw) == 128128
+    ops.gemm_nt(xd, wf, out, b * mpi, C, 9 * C, rmap, 9 * C, C, **kw)
+    plain = torch.zeros_like(out)
+    ops.gemm_nt(xd, wf, plain, b * mpi, C, 9 * C, rmap, 9 * C, C, tile=128128)
+    assert relerr(out.float(), plain.float() + rd.float()) < 8e-3
+    o64 = out.double().view(b, -1)
+    fsum = sums.double() / 2 ** 24
+    assert relerr(fsum[:, 0], o64.sum(1)) < 1e-5 and relerr(fsum[:, 1], (o64 * o64).sum(1)) < 1e-5
+    for tile in (256256, 256009):
+        with pytest.raises(Nn.TheiaNativeError, match="ln_sums together with resid"):
+            ops.gemm_nt(xd, wf, out, b * mpi, C, 9 * C, rmap, 9 * C, C, tile=tile, **kw)

@@ -293,7 +293,14 @@ static int gemm_nt_plan(const theia_gemm_args_t* a, int dtype) {
     const int esz = dtype == THEIA_FP8 ? 1 : dtype == THEIA_BF16 ? 2 : 4;
     const bool pp_ok = a->K % hkt == 0 && a->map.in_c % hkt == 0 && (int64_t)a->map.in_c * esz <= 16384;  // one tap's row fits the zero page
     const bool conv_ok = dtype != THEIA_FP8 && theia_gemm_conv_pp_match(a, dtype, nullptr);
+    // The ping-pong kernels' statistics-emitting instantiations carry no residual / aux_in prefetch (with it they spill registers):
+    // a launch that wants both -- none of the reference's layers does -- runs on the 2-stage 128x128 kernel.
+    const bool sums_and_prefetch = a->ln_sums != nullptr && (a->resid != nullptr || a->act == THEIA_ACT_MUL_DGELU || a->act == THEIA_ACT_MUL_DRELU);
     if (dtype == THEIA_FP8) {  // fp8 operands exist for the ping-pong kernel only
+        if (sums_and_prefetch) {
+            theia_set_error("theia_gemm_nt(fp8): ln_sums together with resid / aux_in is not available");
+            return THEIA_ERR_UNSUPPORTED;
+        }
         if (!pp_ok || (a->tile != 0 && a->tile != 256256)) {
             theia_set_error("theia_gemm_nt(fp8): needs K and in_c multiples of 64 and the 256x256 ping-pong kernel (K=%d in_c=%d tile=%d)", a->K,
                             a->map.in_c, a->tile);
@@ -310,6 +317,11 @@ static int gemm_nt_plan(const theia_gemm_args_t* a, int dtype) {
         theia_set_error("theia_gemm_nt: tile request 256009 needs a 3x3 stride-1 convolution row map with one 16x16 image per 256-row tile");
         return THEIA_ERR_UNSUPPORTED;
     }
+    if (sums_and_prefetch && (a->tile == 256009 || a->tile == 256256)) {
+        theia_set_error("theia_gemm_nt: ln_sums together with resid / aux_in is not available on the 256x256 ping-pong kernels (tile request %d)", a->tile);
+        return THEIA_ERR_UNSUPPORTED;
+    }
+    if (sums_and_prefetch && tile == 256256) return 128128;
     if (a->tile == 256009) return 256009;
     if (a->tile == 256256) return 256256;
     if (tile == 256256) {

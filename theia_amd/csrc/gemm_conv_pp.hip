@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
 
     float* ep = reinterpret_cast<float*>(smem) + wave * (64 * (WN + 4));
     const bool prefetch = sizeof(T) == 2 && (p.resid != nullptr || p.act == THEIA_ACT_MUL_DGELU || p.act == THEIA_ACT_MUL_DRELU);
-    if constexpr (SUMS) gt_epilogue<T, WM, WN, true, false, 4, -1>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);  // see gemm_pp.hip
+    if constexpr (SUMS) gt_epilogue<T, WM, WN, true, false, 4, 0>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);  // see gemm_pp.hip
     else if (prefetch) gt_epilogue<T, WM, WN, false, false, 4, 1>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
     else gt_epilogue<T, WM, WN, false, false, 4, 0>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
 }

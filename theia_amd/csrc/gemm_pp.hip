@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
     const bool prefetch = sizeof(OutT) == 2 && (p.resid != nullptr || p.act == THEIA_ACT_MUL_DGELU || p.act == THEIA_ACT_MUL_DRELU);
     // (the statistics-emitting instantiation keeps ONE epilogue that decides at run time: with two the register allocation of its
     // main loop spills -- the stride-2 transposed convolutions ran 2x slower)
-    if constexpr (SUMS) gt_epilogue<OutT, WM, WN, true, sizeof(T) == 1, 4, -1>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
+    if constexpr (SUMS) gt_epilogue<OutT, WM, WN, true, sizeof(T) == 1, 4, 0>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
     else if (prefetch) gt_epilogue<OutT, WM, WN, false, sizeof(T) == 1, 4, 1>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
     else gt_epilogue<OutT, WM, WN, false, sizeof(T) == 1, 4, 0>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
     PP_PHASE(5)

@@ -177,27 +177,33 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
     const int64_t d_wy = mp.out_batch_stride - mp.rows_h * row_pitch;
     int dead_ry, dead_rx;
     const int64_t off_dead = decode_row(0, dead_ry, dead_rx);  // where dead lanes (rows >= M, columns >= N) prefetch from: row 0, column 0
-    int m_cur = m_wave0 + lrow, cur_ry, cur_rx;
-    int64_t off_cur = decode_row(m_cur, cur_ry, cur_rx) + n;
-    auto next_row = [&]() {  // advance this lane's row by RPP
-        m_cur += RPP;
+    struct row_cursor_t { int m, ry, rx; int64_t off; };
+    auto first_row = [&]() {
+        row_cursor_t c;
+        c.m = m_wave0 + lrow;
+        c.off = decode_row(c.m, c.ry, c.rx) + n;
+        return c;
+    };
+    auto next_row = [&](row_cursor_t& c) {  // advance this lane's row by RPP
+        c.m += RPP;
         if (step_mode == 2) {
-            off_cur = decode_row(m_cur, cur_ry, cur_rx) + n;
+            c.off = decode_row(c.m, c.ry, c.rx) + n;
             return;
         }
-        off_cur += d_step;
+        c.off += d_step;
         if (step_mode == 1) {
-            cur_rx += step_rw;
-            cur_ry += step_qw;
-            const bool wx = cur_rx >= mp.rows_w;
-            cur_rx -= wx ? mp.rows_w : 0;
-            cur_ry += wx ? 1 : 0;
-            off_cur += wx ? d_wx : 0;
-            const bool wy = cur_ry >= mp.rows_h;
-            cur_ry -= wy ? mp.rows_h : 0;
-            off_cur += wy ? d_wy : 0;
+            c.rx += step_rw;
+            c.ry += step_qw;
+            const bool wx = c.rx >= mp.rows_w;
+            c.rx -= wx ? mp.rows_w : 0;
+            c.ry += wx ? 1 : 0;
+            c.off += wx ? d_wx : 0;
+            const bool wy = c.ry >= mp.rows_h;
+            c.ry -= wy ? mp.rows_h : 0;
+            c.off += wy ? d_wy : 0;
         }
     };
+    row_cursor_t cur = first_row();
     auto unpack8 = [](const gt_u32x4& u, float (&f)[8]) {
         const uint32_t w4[4] = {u[0], u[1], u[2], u[3]};
 #pragma unroll
@@ -206,17 +212,22 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
             f[2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u);
         }
     };
-    // Passes are processed in groups of GP: the residual / aux_in rows of group g+1 are requested before group g's
-    // stores are issued.  vmcnt retires in order, so a load that follows a store waits for that store's acknowledgement
-    // (~1.7k cycles under load); one such wait per GROUP instead of one per pass.  Without residual / aux_in the loop has no
-    // vector-memory wait at all and the stores just stream out.
+    // Passes are processed in groups of GP.  The residual / aux_in rows (bf16) of ALL passes are requested before the first store
+    // of the tile and waited for once with vmcnt(0): loads and stores share the vmcnt counter but do not retire in order with
+    // respect to each other, so a counted wait cannot tell a landed load from an acknowledged store (an earlier version requested
+    // group g+1's rows ahead of group g's stores and waited with vmcnt(GP): wrong rows whenever the stores were acknowledged
+    // first -- caught by ln_sums + resid on the 128x128 kernel), and a load issued behind stores waits for their acknowledgements
+    // (~1.7-4k cycles under load).  Order: rows of the first LDS half -> stage that half's accumulators (their registers are then
+    // free) -> rows of the second half -> one wait.  The loop below has no vector-memory wait at all; the stores just stream out.
     constexpr int GP = NPS < GPMAX ? NPS : GPMAX;      // passes per group (unrolled: static registers for the prefetched rows)
     constexpr int NG = WM / RPP / GP;          // groups per wave tile
     constexpr int GPH = NPS / GP;              // groups per LDS half
     static_assert(GP == 8 || GP == 4 || GP == 2, "explicit waits below are written for 2, 4 or 8 passes per group");
+    static_assert(WM / EPH == 1 || WM / EPH == 2, "one or two LDS halves per wave tile");
     bool nlive[GP];
     int64_t noff[GP];
-    gt_u32x4 npre[GP];
+    constexpr int NPRE = PREF == 0 ? GP : NPS;
+    gt_u32x4 pre_cur[NPRE], pre_nxt[NPRE];     // prefetched rows of the current / the second LDS half (slot 0 = next pass)
     // optional per-image (sum, sum of squares) of the stored values (theia_gemm_args_t.ln_sums): a wave tile of WM <= 128 rows
     // touches at most two images (rows per image >= 128, checked by the dispatch): slot 0 = the image of the tile's first row
     unsigned long long* const lsum = SUMS ? reinterpret_cast<unsigned long long*>(p.ln_sums) : nullptr;
@@ -228,58 +239,71 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
     // vmcnt(0) at their first use, i.e. also for every store issued since.  The explicit counted waits below (tied to the
     // registers by "+v") are the only synchronisation of npre[].  Every pass issues its output store unconditionally
     // (dead lanes store to a dump page), so at least GP vector-memory operations follow a group's prefetch.
-    auto fetch_group = [&](int g) {
+    auto fetch_group = [&](int g) {  // rows of group g (offsets and liveness; the prefetched data is already in pre_all)
 #pragma unroll
         for (int q = 0; q < GP; ++q) {
-            nlive[q] = (m_cur < p.M) && n_ok;
-            noff[q] = nlive[q] ? off_cur : off_dead;
-            next_row();
-            npre[q] = (gt_u32x4){0u, 0u, 0u, 0u};
-            if (PREF == 1 || pre_on)  // wave-uniform; dead lanes read row 0 (valid memory)
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(npre[q]) : "v"(PRE + noff[q]) : "memory");
+            nlive[q] = (cur.m < p.M) && n_ok;
+            noff[q] = nlive[q] ? cur.off : off_dead;
+            next_row(cur);
         }
     };
-    // wait until at most N vector-memory operations are outstanding, tied to the prefetch registers
-#define GT_WAIT_PRE(N)                                                                                                                            \
-    do {                                                                                                                                          \
-        if constexpr (GP == 8)                                                                                                                    \
-            asm volatile("s_waitcnt vmcnt(%8)"                                                                                                    \
-                         : "+v"(npre[0]), "+v"(npre[1]), "+v"(npre[2]), "+v"(npre[3]), "+v"(npre[GP - 4]), "+v"(npre[GP - 3]), "+v"(npre[GP - 2]), \
-                           "+v"(npre[GP - 1])                                                                                                     \
-                         : "n"(N)                                                                                                                 \
-                         : "memory");                                                                                                             \
-        else if constexpr (GP == 4)                                                                                                               \
-            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(npre[0]), "+v"(npre[1]), "+v"(npre[2]), "+v"(npre[3]) : "n"(N) : "memory");                 \
-        else                                                                                                                                      \
-            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(npre[0]), "+v"(npre[1]) : "n"(N) : "memory");                                               \
-    } while (0)
+    // accumulators of EPH rows -> wave-private LDS tile (static register indices: one copy per half, selected by a wave-uniform
+    // branch)
+    auto stage_half = [&](int half) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int hf = 0; hf < WM / EPH; ++hf) {
+            if (half != hf) continue;
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int jj = 0; jj < EPH / 16; ++jj) {
+                    const int j = hf * (EPH / 16) + jj;
+                    float* q = ep + (jj * 16 + frow) * EP_PITCH + i * 16 + fg * 4;
+                    *reinterpret_cast<float4*>(q) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+    };
     GT_EP_STAMP(0)
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) pre_cur[i] = pre_nxt[i] = (gt_u32x4){0u, 0u, 0u, 0u};
+    const bool prefetch = PREF == 1 || pre_on;  // wave-uniform
+    row_cursor_t pc = first_row();
+    auto request_half = [&](gt_u32x4 (&dst)[NPRE]) {  // dead lanes read row 0 (valid memory)
+#pragma unroll
+        for (int i = 0; i < NPS; ++i) {
+            const bool lv = (pc.m < p.M) && n_ok;
+            const int64_t po = lv ? pc.off : off_dead;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[PREF == 0 ? 0 : i]) : "v"(PRE + po) : "memory");
+            next_row(pc);
+        }
+    };
+    if (prefetch) request_half(pre_cur);
+    stage_half(0);
+    if (prefetch) {
+        if (WM / EPH > 1) request_half(pre_nxt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NPS; ++i) {  // uses of the rows stay behind the wait
+            asm volatile("" : "+v"(pre_cur[PREF == 0 ? 0 : i]));
+            asm volatile("" : "+v"(pre_nxt[PREF == 0 ? 0 : i]));
+        }
+    }
     fetch_group(0);
-    if constexpr (PREF != 0) GT_WAIT_PRE(0);
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // the same vmcnt(0), visible to the compiler: the bias row has landed too
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), visible to the compiler: the bias row has landed too
     T* const dump = reinterpret_cast<T*>(g_gt_dump) + lane * 8;
     GT_EP_STAMP(1)
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
         GT_EP_STAMP(2 + 3 * (g & 3))
-        if (g % GPH == 0) {
-            // accumulators of the next EPH rows -> wave-private LDS tile (static register indices: one copy per half,
-            // selected by a wave-uniform branch)
-            __builtin_amdgcn_wave_barrier();
+        if (g != 0 && g % GPH == 0) {  // second half (the first was staged above)
+            stage_half(g / GPH);
+            if constexpr (PREF != 0) {
 #pragma unroll
-            for (int hf = 0; hf < WM / EPH; ++hf) {
-                if (g / GPH != hf) continue;
-#pragma unroll
-                for (int i = 0; i < FN; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < EPH / 16; ++jj) {
-                        const int j = hf * (EPH / 16) + jj;
-                        float* q = ep + (jj * 16 + frow) * EP_PITCH + i * 16 + fg * 4;
-                        *reinterpret_cast<float4*>(q) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                    }
+                for (int i = 0; i < NPRE; ++i) pre_cur[i] = pre_nxt[i];
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-            __builtin_amdgcn_wave_barrier();
         }
         GT_EP_STAMP(3 + 3 * (g & 3))
         bool live[GP];
@@ -289,7 +313,11 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
         for (int q = 0; q < GP; ++q) {
             live[q] = nlive[q];
             off[q] = noff[q];
-            pre[q] = npre[q];
+            pre[q] = pre_cur[q];
+        }
+        if constexpr (PREF != 0) {  // the half's remaining rows move up one group
+#pragma unroll
+            for (int i = 0; i + GP < NPRE; ++i) pre_cur[i] = pre_cur[i + GP];
         }
         if (g + 1 < NG) fetch_group(g + 1);
 #pragma unroll
@@ -358,7 +386,6 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
         // prefetch there is nothing to wait for: the stores of all groups stream out back to back (a wait here would hold every
         // group until the previous group's stores are ACKNOWLEDGED, ~4k cycles each when all CUs are in their epilogues at once)
         GT_EP_STAMP(4 + 3 * (g & 3))
-        if constexpr (PREF != 0) GT_WAIT_PRE(GP);
     }
     GT_EP_STAMP(14)
     if constexpr (SUMS) {
