@@ -30,8 +30,10 @@ __device__ __forceinline__ uint4 wp_tr_frag(const char* __restrict__ part, int l
 }
 
 // FAST: constant-step row addressing (see below); the host picks the instantiation, so the hot loop carries one path only
-template <bool FAST>
+// SPLIT_ISSUE: where the LDS-DMA of half-step h+3 is issued (A/B switch THEIA_WGRAD_ISSUE=m: both rows in the M segment)
+template <bool FAST, bool SPLIT_ISSUE = true>
 __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_args_t p) {
+    constexpr bool wgrad_split_issue = SPLIT_ISSUE;
     constexpr int NSTAGE = 4, MS = 32, ROWB = 512, PART = MS * ROWB, STAGE = 2 * PART;
     constexpr int FM = 8, FN = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -197,8 +199,14 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
             for (int i = 0; i < FN; ++i) fb[i] = wp_tr_frag(sy, wn * 4 + i, lane);
 #pragma unroll
             for (int j = 0; j < FM; ++j) fa[j] = wp_tr_frag(sx, wm * 8 + j, lane);
+            // Row 0 of half-step h+3 is issued here, row 1 between the MFMAs below: an issue_row is 2 LDS-DMA instructions (~100
+            // issue cycles each) + ~40 VALU.  With both in the M segment it was ~1200 cycles against ~600 for R -- the matrix pipe 40 %
+            // busy (PMC) -- since the other group's R segment cannot run longer than this group's M; one in each balances them.
+            if (wgrad_split_issue) issue_row(0, nslot);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // half-step h+1 landed; h+2 may still be in flight
+            // half-step h+1 landed; h+2 (4 operations) and, when issued above, row 0 of h+3 (2) may still be in flight
+            if (wgrad_split_issue) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -208,8 +216,8 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
             for (int j = 0; j < FM; ++j) {
 #pragma unroll
                 for (int i = 0; i < FN; ++i) GtMma<bf16_t>::run(acc[i][j], fa[j], fb[i]);
-                if (j == 0) issue_row(0, nslot);
-                if (j == 4) issue_row(1, nslot);
+                if (!wgrad_split_issue && j == 0) issue_row(0, nslot);
+                if (j == (wgrad_split_issue ? 2 : 4)) issue_row(1, nslot);
             }
             if (do_bias) {
 #pragma unroll
@@ -269,6 +277,7 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int tiles = cdiv_i(a->N, 256) * a->map.ntaps * (a->map.in_c / 256);
@@ -279,7 +288,13 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
     }
     const int R_img = a->map.rows_h * a->map.rows_w;
     const bool fast = allow_fast && ((32 % R_img) == 0 || 32 / a->map.rows_w + 1 <= a->map.rows_h);
-    if (fast) hipLaunchKernelGGL(gemm_wgrad_pp_kernel<true>, dim3(tiles * a->splits), dim3(512), lds, stream, *a);
+    static int issue_in_m = -1;
+    if (issue_in_m < 0) {
+        const char* e = getenv("THEIA_WGRAD_ISSUE");
+        issue_in_m = (e != nullptr && strcmp(e, "m") == 0) ? 1 : 0;
+    }
+    if (fast && issue_in_m) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, false>), dim3(tiles * a->splits), dim3(512), lds, stream, *a);
+    else if (fast) hipLaunchKernelGGL(gemm_wgrad_pp_kernel<true>, dim3(tiles * a->splits), dim3(512), lds, stream, *a);
     else hipLaunchKernelGGL(gemm_wgrad_pp_kernel<false>, dim3(tiles * a->splits), dim3(512), lds, stream, *a);
     THEIA_CHECK_LAUNCH("theia_gemm_wgrad(pp)");
     if (a->bias_out != nullptr && a->defer_bias_reduce == 0) {
