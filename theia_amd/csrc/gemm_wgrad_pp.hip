@@ -96,6 +96,13 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     const int64_t ox_step = whole_images ? (int64_t)(MS / R_img) * mp.in_batch_stride : q32 * ox_row + r32 * ox_pix;
     const int64_t oy_wx = oy_row - mp.rows_w * oy_pix, ox_wx = ox_row - mp.rows_w * ox_pix;                       // rx wrapped: one row down
     const int64_t oy_wy = mp.out_batch_stride - mp.rows_h * oy_row, ox_wy = mp.in_batch_stride - mp.rows_h * ox_row;  // ry wrapped: next image
+    // byte steps as 32-bit values (the host takes this instantiation only when they fit), selected per lane with one v_cndmask each
+    const int32_t by_step = (int32_t)(oy_step * 2), by_wx = (int32_t)(oy_wx * 2), by_wy = (int32_t)(oy_wy * 2);
+    const int32_t bx_step = (int32_t)(ox_step * 2), bx_wx = (int32_t)(ox_wx * 2), bx_wy = (int32_t)(ox_wy * 2);
+    // the tap is fixed per workgroup: "input pixel inside the image" is a range test on the row's (y, x) -- no multiplication
+    const int ry_lo = dy >= 0 ? 0 : (-dy + mp.in_sy - 1) / mp.in_sy, ry_hi = dy >= mp.in_h ? 0 : (mp.in_h - dy + mp.in_sy - 1) / mp.in_sy;
+    const int rx_lo = dx >= 0 ? 0 : (-dx + mp.in_sx - 1) / mp.in_sx, rx_hi = dx >= mp.in_w ? 0 : (mp.in_w - dx + mp.in_sx - 1) / mp.in_sx;
+    const unsigned ry_span = ry_hi > ry_lo ? (unsigned)(ry_hi - ry_lo) : 0u, rx_span = rx_hi > rx_lo ? (unsigned)(rx_hi - rx_lo) : 0u;
     uint64_t f_py[2], f_px[2];   // addresses of the row's dY / activation piece (valid or not)
     if constexpr (fast) {
 #pragma unroll
@@ -113,8 +120,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
         const bool mok = st_m[i] < m_limit;
         uint64_t sy, sx;
         if constexpr (fast) {
-            const int iy = st_ry[i] * mp.in_sy + dy, ix = st_rx[i] * mp.in_sx + dx;
-            const bool xok = mok & ((unsigned)iy < (unsigned)mp.in_h) & ((unsigned)ix < (unsigned)mp.in_w);
+            const bool xok = mok & ((unsigned)(st_ry[i] - ry_lo) < ry_span) & ((unsigned)(st_rx[i] - rx_lo) < rx_span);
             sy = (mok & n_ok) ? f_py[i] : zp;
             sx = xok ? f_px[i] : zp;
         } else {
@@ -140,8 +146,8 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
             ry = wy ? ry - mp.rows_h : ry;
             st_rx[i] = rx;
             st_ry[i] = ry;
-            f_py[i] += (uint64_t)(oy_step + (wx ? oy_wx : 0) + (wy ? oy_wy : 0)) * sizeof(bf16_t);
-            f_px[i] += (uint64_t)(ox_step + (wx ? ox_wx : 0) + (wy ? ox_wy : 0)) * sizeof(bf16_t);
+            f_py[i] += (uint64_t)(int64_t)(by_step + (wx ? by_wx : 0) + (wy ? by_wy : 0));
+            f_px[i] += (uint64_t)(int64_t)(bx_step + (wx ? bx_wx : 0) + (wy ? bx_wy : 0));
             return;
         }
         // general advance: m += 32  ->  (rx, ry, img) with float-reciprocal wraps (operands < 2^12, one correction each)
@@ -287,7 +293,13 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
         allow_fast = (e != nullptr && strcmp(e, "general") == 0) ? 0 : 1;
     }
     const int R_img = a->map.rows_h * a->map.rows_w;
-    const bool fast = allow_fast && ((32 % R_img) == 0 || 32 / a->map.rows_w + 1 <= a->map.rows_h);
+    // the stepping instantiation keeps its address steps (bytes) in 32 bits: one map row / one image of either operand below 1 GiB
+    const int64_t step_lim = (int64_t)1 << 29;  // elements
+    const bool steps_fit = (int64_t)a->map.out_batch_stride * (R_img >= 32 ? 1 : 32 / (R_img > 0 ? R_img : 1)) < step_lim &&
+                           (int64_t)a->map.in_batch_stride * (R_img >= 32 ? 1 : 32 / (R_img > 0 ? R_img : 1)) < step_lim &&
+                           (int64_t)a->map.out_sy * a->map.out_w * a->ldo * (a->map.rows_h + 33) < step_lim &&
+                           (int64_t)a->map.in_sy * a->map.in_w * a->map.in_c * (a->map.rows_h + 33) < step_lim;
+    const bool fast = allow_fast && steps_fit && ((32 % R_img) == 0 || 32 / a->map.rows_w + 1 <= a->map.rows_h);
     static int issue_in_m = -1;
     if (issue_in_m < 0) {
         const char* e = getenv("THEIA_WGRAD_ISSUE");
