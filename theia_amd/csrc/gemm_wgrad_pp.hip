@@ -32,7 +32,7 @@ __device__ __forceinline__ uint4 wp_tr_frag(const char* __restrict__ part, int l
 // FAST: constant-step row addressing (see below); the host picks the instantiation, so the hot loop carries one path only
 // SPLIT_ISSUE: where the LDS-DMA of half-step h+3 is issued (A/B switch THEIA_WGRAD_ISSUE=m: both rows in the M segment)
 template <bool FAST, bool SPLIT_ISSUE = true>
-__global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_args_t p) {
+__global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_args_t p, const int plain_order) {
     constexpr bool wgrad_split_issue = SPLIT_ISSUE;
     constexpr int NSTAGE = 4, MS = 32, ROWB = 512, PART = MS * ROWB, STAGE = 2 * PART;
     constexpr int FM = 8, FN = 4;
@@ -45,7 +45,10 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     const int tiles_n = (p.N + 255) / 256;
     const int tiles_c = mp.in_c / 256;
     const int ntile = tiles_n * mp.ntaps * tiles_c;
-    const int tile = blockIdx.x % ntile, split = blockIdx.x / ntile;
+    // hardware places block b on XCD b % 8: give each XCD a contiguous range of (split, tile) so that the workgroups sharing a dY
+    // column tile or an activation (tap, c) tile meet in one L2 (THEIA_WGRAD_XCD=0: A/B switch, plain order)
+    const int bid = plain_order ? (int)blockIdx.x : gt_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = bid % ntile, split = bid / ntile;
     const int tn = tile % tiles_n, tk = tile / tiles_n;
     const int tap = tk / tiles_c, c0 = (tk - tap * tiles_c) * 256, n0 = tn * 256;
     const int dy = mp.dy[tap], dx = mp.dx[tap];
@@ -305,9 +308,14 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
         const char* e = getenv("THEIA_WGRAD_ISSUE");
         issue_in_m = (e != nullptr && strcmp(e, "m") == 0) ? 1 : 0;
     }
-    if (fast && issue_in_m) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, false>), dim3(tiles * a->splits), dim3(512), lds, stream, *a);
-    else if (fast) hipLaunchKernelGGL(gemm_wgrad_pp_kernel<true>, dim3(tiles * a->splits), dim3(512), lds, stream, *a);
-    else hipLaunchKernelGGL(gemm_wgrad_pp_kernel<false>, dim3(tiles * a->splits), dim3(512), lds, stream, *a);
+    static int plain_order = -1;
+    if (plain_order < 0) {
+        const char* e = getenv("THEIA_WGRAD_XCD");
+        plain_order = (e != nullptr && strcmp(e, "0") == 0) ? 1 : 0;
+    }
+    if (fast && issue_in_m) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, false>), dim3(tiles * a->splits), dim3(512), lds, stream, *a, plain_order);
+    else if (fast) hipLaunchKernelGGL(gemm_wgrad_pp_kernel<true>, dim3(tiles * a->splits), dim3(512), lds, stream, *a, plain_order);
+    else hipLaunchKernelGGL(gemm_wgrad_pp_kernel<false>, dim3(tiles * a->splits), dim3(512), lds, stream, *a, plain_order);
     THEIA_CHECK_LAUNCH("theia_gemm_wgrad(pp)");
     if (a->bias_out != nullptr && a->defer_bias_reduce == 0) {
         hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv_i(a->N, 256)), dim3(256), 0, stream, a->bias_slabs, a->splits, a->N,
