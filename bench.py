@@ -255,10 +255,16 @@ def src_sha(files):
 NT_KERNEL_SOURCES = ["theia_amd/csrc/gemm_pp.hip", "theia_amd/csrc/gemm_tile.h", "theia_amd/csrc/gemm.hip"]
 
 
-def load_traffic(pfx):
+TRAFFIC_WORKLOAD = ("facebook/deit-base-patch16-224", 128, "bf16")  # what tools/pmc_bench_traffic.sh profiles: the default run
+
+
+def load_traffic(pfx, workload=TRAFFIC_WORKLOAD):
     """HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read inside a timed run, so the number
     comes from the committed summary of tools/pmc_bench_traffic.sh -- and only if that summary was taken from the kernel
-    sources this run was built from (it records their hash); otherwise null."""
+    sources this run was built from (it records their hash) and on this run's workload (the default one: the mean over a
+    step's launches depends on its shapes); otherwise null."""
+    if tuple(workload) != TRAFFIC_WORKLOAD:
+        return None, None
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -482,7 +488,7 @@ def main(argv=None):
             iso_tf = achieved
         kname = (f"gemm_nt_pp_kernel<{pfx}> (theia_gemm_nt, 256x256 ping-pong tile)" if dom_var == "256x256"
                  else f"gemm_nt_kernel<{pfx},{dom_var.replace('x', ',')}> (theia_gemm_nt)")
-        traffic, traffic_src = load_traffic(pfx) if dom_var == "256x256" else (None, None)
+        traffic, traffic_src = load_traffic(pfx, (args.backbone, b, args.precision)) if dom_var == "256x256" else (None, None)
         roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK / 1e12,
                     "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": len(dom) // NP, "avg_launch_us": round(tsum / len(dom) * 1e6, 1),
