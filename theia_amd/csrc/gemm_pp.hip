@@ -111,11 +111,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         w_base[i] = (int64_t)n * p.ldw;
     }
 
-    gt_f32x4 acc[FN][FM];
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j) acc[i][j] = (gt_f32x4){0.f, 0.f, 0.f, 0.f};
+    gt_f32x4 acc[FN][FM];  // zeroed below, behind the prologue's LDS-DMA issues (128 v_mov per wave: hidden in the operands' latency)
 
     const int nh = (p.K + HKT - 1) / HKT;   // host guarantees K % HKT == 0 for this kernel
     const uint64_t zp = reinterpret_cast<uint64_t>(g_pp_zero_page);
@@ -165,6 +161,15 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         for (int q = 0; q < LPH; ++q) issue_piece(q, coff, sa, sa + BM * 64);
     }
     PP_PHASE(2)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            acc[i][j] = (gt_f32x4){0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+v"(acc[i][j]));  // materialise the zeros HERE (the compiler otherwise sinks them behind the wait)
+        }
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPH) : "memory");  // half-tile 0 landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
