@@ -235,11 +235,8 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
     img0 = gt_divmod(m_wave0 < p.M ? m_wave0 : 0, R, rcp_R, dummy_rem);
     const int m_split = (img0 + 1) * R;  // first GEMM row of the second image
     float ls0 = 0.f, lq0 = 0.f, ls1 = 0.f, lq1 = 0.f;
-    // The prefetch loads are inline asm, invisible to the compiler's waitcnt bookkeeping: it would otherwise wait with
-    // vmcnt(0) at their first use, i.e. also for every store issued since.  The explicit counted waits below (tied to the
-    // registers by "+v") are the only synchronisation of npre[].  Every pass issues its output store unconditionally
-    // (dead lanes store to a dump page), so at least GP vector-memory operations follow a group's prefetch.
-    auto fetch_group = [&](int g) {  // rows of group g (offsets and liveness; the prefetched data is already in pre_all)
+    // Every pass issues its output store unconditionally (dead lanes store to a dump page).
+    auto fetch_group = [&](int g) {  // rows of group g: offsets and liveness (the prefetched data is already in pre_cur)
 #pragma unroll
         for (int q = 0; q < GP; ++q) {
             nlive[q] = (cur.m < p.M) && n_ok;
