@@ -686,6 +686,18 @@ def test_transpose_acc_and_wgrad_finish_layouts():
             got = view(out).reshape(Nn_, kslots, C)
             assert relerr(got, want + (0.25 if acc else 0.0)) < 1e-6
             assert relerr(bout, bpart.sum(0) + (0.25 if acc else 0.0)) < 1e-6
+    # nn.Linear gradients take the row kernel (16-byte reduction, no LDS): real sizes, strided output rows (the fused q/k/v
+    # gradient writes [3D][D] slices), and the sizes that must fall back to the tiled kernel (C not a multiple of 4)
+    for Nn2, C2, sn2, sp in ((768, 3072, 3072, 7), (2304, 768, 768, 9), (96, 64, 80, 5), (33, 70, 70, 3), (40, 66, 72, 2)):
+        slabs = h((sp, Nn2, C2), 31 + sp).to(dev)
+        want = slabs[0].clone()
+        for k in range(1, sp):
+            want += slabs[k]  # the kernel's order: split 0 first
+        for acc in (False, True):
+            out = torch.full((Nn2, sn2), 0.25, device=dev)
+            ops.wgrad_finish(slabs, sp, Nn2, 1, C2, out, sn2, 0, 1, acc)
+            assert torch.equal(out[:, :C2], want + 0.25 if acc else want), (Nn2, C2, sn2, acc)
+            assert bool((out[:, C2:] == 0.25).all())  # the padding between rows is not touched
 
 
 def test_fp8_quantize_and_scale_update():

@@ -702,28 +702,52 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
         }
         return;
     }
-    const int tiles_c = (C + TC - 1) / TC;
+    // TN, TC are powers of two (host); kslots <= 16: float-reciprocal division (operands far below 2^24)
+    const int LC = 31 - __builtin_clz(TC), LN = 31 - __builtin_clz(TN);
+    const float rcp_k = 1.0f / (float)kslots;
+    const int tiles_c = (C + TC - 1) >> LC;
     const int n0 = ((int)blockIdx.x / tiles_c) * TN, c0 = ((int)blockIdx.x % tiles_c) * TC;
     const int64_t krow = (int64_t)kslots * C, total = (int64_t)N * krow;
     const int pitch = TC + 1;
     const int per = TN * kslots * TC;
-    for (int i = threadIdx.x; i < per; i += 256) {
-        const int cc = i % TC, r = i / TC;
-        const int slot = r % kslots, nn = r / kslots;
-        float s = 0.f;
-        if (n0 + nn < N && c0 + cc < C) {
-            const int64_t idx = (int64_t)(n0 + nn) * krow + (int64_t)slot * C + c0 + cc;
-            for (int k = 0; k < splits; ++k) s += slabs[(int64_t)k * total + idx];
+    const bool vec = (C & 3) == 0 && (reinterpret_cast<uint64_t>(slabs) & 15) == 0;  // c0, TC are multiples of 4
+    if (vec) {  // 4 consecutive channels per lane: 16-byte slab reads
+        for (int i = threadIdx.x * 4; i < per; i += 1024) {
+            const int cc = i & (TC - 1), r = i >> LC;
+            int slot;
+            const int nn = gt_divmod(r, kslots, rcp_k, slot);
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0 + nn < N && c0 + cc < C) {
+                const int64_t idx = (int64_t)(n0 + nn) * krow + (int64_t)slot * C + c0 + cc;
+                for (int k = 0; k < splits; ++k) {
+                    const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)k * total + idx);
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+            }
+            float* d = lds + (nn * kslots + slot) * pitch + cc;
+            d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w;
         }
-        lds[(nn * kslots + slot) * pitch + cc] = s;
+    } else {
+        for (int i = threadIdx.x; i < per; i += 256) {
+            const int cc = i & (TC - 1), r = i >> LC;
+            int slot;
+            const int nn = gt_divmod(r, kslots, rcp_k, slot);
+            float s = 0.f;
+            if (n0 + nn < N && c0 + cc < C) {
+                const int64_t idx = (int64_t)(n0 + nn) * krow + (int64_t)slot * C + c0 + cc;
+                for (int k = 0; k < splits; ++k) s += slabs[(int64_t)k * total + idx];
+            }
+            lds[(nn * kslots + slot) * pitch + cc] = s;
+        }
     }
     __syncthreads();
     // output order: slot fastest when ss == 1 (kslots > 1), then the smaller of (sc, sn)
     const bool c_mid = sc <= sn;  // [n][c][slot] (Conv2d) vs [c][n][slot] (ConvTranspose2d stride 1); Linear: kslots = 1, c_mid
     for (int i = threadIdx.x; i < per; i += 256) {
-        const int slot = i % kslots, r = i / kslots;
+        int slot;
+        const int r = gt_divmod(i, kslots, rcp_k, slot);
         int nn, cc;
-        if (c_mid) { cc = r % TC; nn = r / TC; } else { nn = r % TN; cc = r / TN; }
+        if (c_mid) { cc = r & (TC - 1); nn = r >> LC; } else { nn = r & (TN - 1); cc = r >> LN; }
         if (n0 + nn < N && c0 + cc < C) {
             const int64_t o = (int64_t)(n0 + nn) * sn + (int64_t)slot * ss + (int64_t)(c0 + cc) * sc;
             const float v = lds[(nn * kslots + slot) * pitch + cc];
@@ -732,18 +756,62 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
     }
 }
 
+// nn.Linear gradients (one slot, channels contiguous in the output: slab order IS output order): a plain 16-byte reduction, no LDS.
+// 48 of the 69 finish launches of a DeiT-base step; the tiled kernel above spent them on 2-element-per-thread blocks.
+__global__ __launch_bounds__(256) void wgrad_finish_rows_kernel(const float* __restrict__ slabs, int splits, int N, int C, float* __restrict__ out,
+                                                                int64_t sn, int accumulate, int wblocks, const float* __restrict__ bias_part,
+                                                                float* __restrict__ bias_out, int bias_accumulate) {
+    if ((int)blockIdx.x >= wblocks) {
+        const int n = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
+        if (n < N) {
+            float s = 0.f;
+            for (int q = 0; q < splits; ++q) s += bias_part[(int64_t)q * N + n];
+            bias_out[n] = bias_accumulate ? bias_out[n] + s : s;
+        }
+        return;
+    }
+    const int c4n = C >> 2;
+    const int64_t total4 = (int64_t)N * c4n, total = (int64_t)N * C;
+    const float rcp = 1.0f / (float)c4n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)wblocks * 256) {
+        float4 s = *reinterpret_cast<const float4*>(slabs + i * 4);
+        for (int k = 1; k < splits; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)k * total + i * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        int c4;
+        const int n = gt_divmod((int)i, c4n, rcp, c4);
+        float4* d = reinterpret_cast<float4*>(out + (int64_t)n * sn + c4 * 4);
+        if (accumulate) {
+            const float4 o = *d;
+            s.x = o.x + s.x; s.y = o.y + s.y; s.z = o.z + s.z; s.w = o.w + s.w;
+        }
+        *d = s;
+    }
+}
+
 extern "C" int theia_wgrad_finish(const float* slabs, int splits, int N, int kslots, int C, float* out, int64_t sn, int64_t ss,
                                   int64_t sc, int accumulate, const float* bias_slabs, float* bias_out, int bias_accumulate,
                                   void* stream) {
     THEIA_CHECK_ARG(slabs && out && splits >= 1 && N > 0 && kslots > 0 && kslots <= 16 && C > 0, "theia_wgrad_finish: bad args");
     THEIA_CHECK_ARG((bias_out == nullptr) == (bias_slabs == nullptr), "theia_wgrad_finish: bias_slabs and bias_out go together");
+    const int btiles = bias_out != nullptr ? cdiv_i(N, 256) : 0;
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    if (kslots == 1 && sc == 1 && (C & 3) == 0 && (sn & 3) == 0 && (int64_t)N * (C >> 2) < ((int64_t)1 << 24) &&
+        ((reinterpret_cast<uint64_t>(slabs) | reinterpret_cast<uint64_t>(out)) & 15) == 0) {
+        int wblocks = (int)(((int64_t)N * (C >> 2) + 255) / 256);
+        if (wblocks > 4096) wblocks = 4096;
+        hipLaunchKernelGGL(wgrad_finish_rows_kernel, dim3(wblocks + btiles), dim3(256), 0, hs, slabs, splits, N, C, out, sn, accumulate, wblocks,
+                           bias_slabs, bias_out, bias_accumulate);
+        THEIA_CHECK_LAUNCH("theia_wgrad_finish");
+        return THEIA_OK;
+    }
     // tile: many channels when c follows the slot in the output (long contiguous runs per n), square-ish when n does
     const bool c_mid = sc <= sn;
     const int TC = c_mid ? 64 : 32, TN = c_mid ? (kslots > 1 ? 4 : 8) : 32;
     const int wtiles = cdiv_i(N, TN) * cdiv_i(C, TC);
-    const int btiles = bias_out != nullptr ? cdiv_i(N, 256) : 0;
     const size_t lds = (size_t)TN * kslots * (TC + 1) * sizeof(float);
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(wtiles + btiles), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), slabs, splits, N,
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(wtiles + btiles), dim3(256), lds, hs, slabs, splits, N,
                        kslots, C, out, sn, ss, sc, accumulate, TN, TC, wtiles, bias_slabs, bias_out, bias_accumulate);
     THEIA_CHECK_LAUNCH("theia_wgrad_finish");
     return THEIA_OK;
