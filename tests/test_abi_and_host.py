@@ -221,3 +221,39 @@ def test_legacy_checkpoint_key_remap():
     assert remap_legacy_key("backbone.model.encoder.layer.11.intermediate.dense.weight") == "backbone.model.layers.11.mlp.fc1.weight"
     assert remap_legacy_key("backbone.model.encoder.layer.11.output.dense.weight") == "backbone.model.layers.11.mlp.fc2.weight"
     assert remap_legacy_key("backbone.model.embeddings.cls_token") == "backbone.model.embeddings.cls_token"
+
+
+def test_kernel_plan_of_a_launch_is_host_logic():
+    """theia_gemm_nt_plan (no launch, no GPU): which kernel a theia_gemm_nt call would run -- the library's own choice for the bench
+    shapes, the 3x3 kernel for one-image-per-tile convolutions, explicit requests honoured or refused (never replaced), and the
+    LayerNorm-statistics epilogue together with a residual routed to the 2-stage kernel."""
+    from theia_amd import _native as N, ops
+    lib = N.lib()
+
+    def plan(M, Nn, K, rmap, dtype=N.BF16, tile=0, ln_sums=0, resid=0, act=N.ACT_NONE, aux_in=0):
+        g = N.GemmArgs()
+        g.a, g.w, g.out = 4096, 8192, 12288  # never dereferenced by the planner
+        g.M, g.N, g.K, g.ldw, g.ldo, g.act, g.tile = M, Nn, K, K, Nn, act, tile
+        g.map = rmap
+        g.ln_sums, g.resid, g.aux_in = ln_sums or None, resid or None, aux_in or None
+        return lib.theia_gemm_nt_plan(g, dtype)
+
+    b, C = 128, 768
+    lin = ops.rm_plain(C, C, C)
+    assert plan(b * 197, C, C, lin) == 256256 and plan(b * 197, C, C, lin, N.F32) == 128128
+    assert plan(64, C, C, lin) in (128128, 128064) and plan(64, C, C, lin, tile=256256) == 256256
+    conv = ops.plan_conv3x3(C, 16)
+    (fmap, mpi), = conv.fwd
+    assert plan(b * mpi, C, 9 * C, fmap) == 256009 and plan(b * mpi, C, 9 * C, conv.dgrad[0]) == 256009
+    assert plan(b * mpi, C, 9 * C, fmap, tile=256256) == 256256 and plan(b * mpi, C, 9 * C, fmap, tile=128128) == 128128
+    up = ops.plan_convT3x3(C, 16, 2, 1, 0)      # stride-2 transposed convolution: parity classes, not one image per tile
+    assert all(plan(b * m, C, r.ntaps * C, r) == 256256 for r, m in up.fwd)
+    assert plan(b * up.fwd[0][1], C, up.fwd[0][0].ntaps * C, up.fwd[0][0], tile=256009) < 0   # refused, not replaced
+    assert plan(b * 197, C, 40, ops.rm_plain(40, 40, C), tile=256256) < 0                     # K not a multiple of 32
+    # LayerNorm statistics + a residual / aux_in row: no such instantiation of the ping-pong kernels
+    assert plan(b * mpi, C, 9 * C, fmap, ln_sums=4096) == 256009
+    assert plan(b * mpi, C, 9 * C, fmap, ln_sums=4096, resid=4096) == 128128
+    assert plan(b * mpi, C, 9 * C, fmap, ln_sums=4096, act=N.ACT_MUL_DRELU, aux_in=4096) == 128128
+    assert plan(b * mpi, C, 9 * C, fmap, ln_sums=4096, resid=4096, tile=256009) < 0
+    assert plan(b * mpi, C, 9 * C, fmap, ln_sums=4096, resid=4096, tile=256256) < 0
+    assert b"ln_sums together with resid" in lib.theia_last_error()
