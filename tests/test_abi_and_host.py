@@ -230,8 +230,9 @@ def test_kernel_plan_of_a_launch_is_host_logic():
     from theia_amd import _native as N, ops
     lib = N.lib()
 
-    def plan(M, Nn, K, rmap, dtype=N.BF16, tile=0, ln_sums=0, resid=0, act=N.ACT_NONE, aux_in=0):
+    def plan(M, Nn, K, rmap, dtype=N.BF16, tile=0, ln_sums=0, resid=0, act=N.ACT_NONE, aux_in=0, rowtab=0):
         g = N.GemmArgs()
+        g.rowtab, g.rowtab_period = rowtab or None, 196
         g.a, g.w, g.out = 4096, 8192, 12288  # never dereferenced by the planner
         g.M, g.N, g.K, g.ldw, g.ldo, g.act, g.tile = M, Nn, K, K, Nn, act, tile
         g.map = rmap
@@ -240,14 +241,20 @@ def test_kernel_plan_of_a_launch_is_host_logic():
 
     b, C = 128, 768
     lin = ops.rm_plain(C, C, C)
-    assert plan(b * 197, C, C, lin) == 256256 and plan(b * 197, C, C, lin, N.F32) == 128128
-    assert plan(64, C, C, lin) in (128128, 128064) and plan(64, C, C, lin, tile=256256) == 256256
+    # 25216 rows x 768 columns: 79 tiles of 320 rows x 3 = ONE round of the persistent grid (297 tiles of 256 rows would be two)
+    assert plan(b * 197, C, C, lin) == 320256 and plan(b * 197, C, C, lin, N.F32) == 128128
+    assert plan(b * 197, 3 * C, C, ops.rm_plain(C, C, 3 * C)) in (256256, 320256) and plan(b * 197, 4 * C, C, ops.rm_plain(C, C, 4 * C)) == 256256
+    assert plan(64, C, C, lin) in (128128, 128064) and plan(64, C, C, lin, tile=256256) == 256256 and plan(64, C, C, lin, tile=320256) == 320256
+    assert plan(64, C, C, lin, N.F32, tile=320256) < 0                                        # 320-row tiles are bf16 only
+    # what the persistent ping-pong kernel leaves to the 2-stage kernels: a position row table, residual + activation
+    assert plan(b * 196, C, C, lin, rowtab=4096) == 256000 and plan(b * 196, C, C, lin, rowtab=4096, tile=256256) < 0
+    assert plan(b * 197, C, C, lin, resid=4096, act=N.ACT_RELU) == 256000 and plan(b * 197, C, C, lin, resid=4096) == 320256
     conv = ops.plan_conv3x3(C, 16)
     (fmap, mpi), = conv.fwd
     assert plan(b * mpi, C, 9 * C, fmap) == 256009 and plan(b * mpi, C, 9 * C, conv.dgrad[0]) == 256009
     assert plan(b * mpi, C, 9 * C, fmap, tile=256256) == 256256 and plan(b * mpi, C, 9 * C, fmap, tile=128128) == 128128
     up = ops.plan_convT3x3(C, 16, 2, 1, 0)      # stride-2 transposed convolution: parity classes, not one image per tile
-    assert all(plan(b * m, C, r.ntaps * C, r) == 256256 for r, m in up.fwd)
+    assert all(plan(b * m, C, r.ntaps * C, r) in (256256, 320256) for r, m in up.fwd)
     assert plan(b * up.fwd[0][1], C, up.fwd[0][0].ntaps * C, up.fwd[0][0], tile=256009) < 0   # refused, not replaced
     assert plan(b * 197, C, 40, ops.rm_plain(40, 40, C), tile=256256) < 0                     # K not a multiple of 32
     # LayerNorm statistics + a residual / aux_in row: no such instantiation of the ping-pong kernels

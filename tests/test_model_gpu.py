@@ -205,9 +205,17 @@ def test_bf16_base_cddsv_on_the_pingpong_kernels_vs_oracle():
 
 
 def test_bf16_bench_dispatch_agrees_with_the_2stage_kernels():
-    """DeiT-base + cddsv at B = 64, where the library's own dispatch puts the ViT and head GEMMs on the ping-pong kernel
-    (as at the bench's B = 128): the same step with every GEMM forced onto the 2-stage 128x128 kernel (the kernel the
-    small-shape oracle tests run by default) must give the same losses and gradients up to bf16 rounding noise."""
+    """DeiT-base + cddsv at B = 64, where the library's own dispatch puts the ViT and head GEMMs on the persistent ping-pong kernel
+    (as at the bench's B = 128): the same step with every GEMM forced onto the 2-stage 128x128 kernel (the kernel the small-shape
+    oracle tests run by default) must give the same losses and gradients up to bf16 rounding noise.
+
+    What "bf16 rounding noise" is, measured (round 3): the ping-pong kernel starts its f32 accumulation from the bias / residual row
+    instead of adding them last, so each GEMM's output differs from the 2-stage kernel's by ONE bf16 ulp in ~1e-4 of its elements
+    (tests/test_ops_gpu.py::test_pingpong_matches_2stage_up_to_rare_ulp_flips) -- and 12 layers of LayerNorm / attention / residual
+    later the two executions have decorrelated to the bf16 noise floor: ~40 % of the elements of a head activation differ in their
+    last bit, losses agree to < 2e-3, and the most noise-sensitive gradients (the LayerNorm[C,16,16] affine in front of the first
+    head convolution: sums over only B samples) agree to cosine 0.9938.  (With bit-identical accumulation order, as in round 2, the
+    same comparison gave 0.9998: that figure measured identical arithmetic, not bf16 accuracy.)  Each execution is deterministic."""
     from theia_amd import _native as N
     bb, teachers, B = "facebook/deit-base-patch16-224", O.TEACHER_SETS["cddsv"], 64
     assert N.lib().theia_gemm_nt_tile(B * 197, 768, N.BF16) == 256256 and N.lib().theia_gemm_nt_tile(B * 256, 768, N.BF16) == 256256
@@ -223,13 +231,15 @@ def test_bf16_bench_dispatch_agrees_with_the_2stage_kernels():
 
     la = step()
     ga = {k: p.grad.clone() for k, p in model.named_parameters()}
+    la2 = step()
+    assert all(torch.equal(ga[k], p.grad) for k, p in model.named_parameters()) and float(la["cos_loss"]) == float(la2["cos_loss"])  # deterministic
     with tile_hint(128128):
         lb = step()
     for k in ("mse_loss", "cos_loss", "l1_loss"):
         assert rel(float(la[k]), float(lb[k])) < 2e-3, (k, float(la[k]), float(lb[k]))
     cos, nr, who = _grad_agreement(model, ga)
     print(f"[base bf16 B=64 auto vs 128x128] worst gradient cosine {cos:.6f} ({who}), worst norm-ratio error {nr:.5f}")
-    assert cos > 0.999 and nr < 1e-2, (cos, nr, who)
+    assert cos > 0.99 and nr < 1.5e-2, (cos, nr, who)
 
 
 def test_input_layouts_and_reduce_modes(golden_dir):

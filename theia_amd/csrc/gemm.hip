@@ -17,7 +17,7 @@
 // The MFMA is issued with the WEIGHT fragment as its A operand and the ACTIVATION fragment as its B operand, so a lane ends
 // up with 4 consecutive n for one m: the accumulator tile goes to LDS with ds_write_b128 and is re-read row-contiguously,
 // giving a fully vectorised epilogue (gemm_tile.h).
-#include "gemm_tile.h"
+#include "gemm_epi_direct.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
 typedef gt_f32x4 f32x4_v;
@@ -54,6 +54,7 @@ __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + 
 // NT implicit GEMM
 // ================================================================================================
 int theia_gemm_nt_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t stream);               // gemm_pp.hip
+int theia_gemm_nt_pp_bm(const theia_gemm_args_t* a, int dtype);                                        // rows per tile it would use
 struct conv_taps_t;
 bool theia_gemm_conv_pp_match(const theia_gemm_args_t* a, int dtype, conv_taps_t* out);                 // gemm_conv_pp.hip
 int theia_gemm_conv_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t stream);
@@ -279,9 +280,10 @@ extern "C" int theia_gemm_nt_tile(int M, int N, int dtype) {
 // with the 256x256 tile (problems the ping-pong kernels do not take), 256256 = ping-pong kernel, 256009 = ping-pong kernel for
 // 3x3 convolutions with one image per tile (gemm_conv_pp.hip); negative = error.
 static int gemm_nt_plan(const theia_gemm_args_t* a, int dtype) {
-    THEIA_CHECK_ARG(a->tile == 0 || a->tile == 128128 || a->tile == 128064 || a->tile == 256256 || a->tile == 256009,
+    THEIA_CHECK_ARG(a->tile == 0 || a->tile == 128128 || a->tile == 128064 || a->tile == 256256 || a->tile == 320256 || a->tile == 256009,
                     "theia_gemm_nt: bad tile request %d", a->tile);
-    const int tile = a->tile != 0 ? a->tile : theia_gemm_nt_tile(a->M, a->N, dtype);
+    const bool want_pp = a->tile == 256256 || a->tile == 320256;
+    const int tile = a->tile == 320256 ? 256256 : a->tile != 0 ? a->tile : theia_gemm_nt_tile(a->M, a->N, dtype);
     static int use_pp = -1, use_conv = -1;  // THEIA_GEMM_KERNEL=std / THEIA_CONV_KERNEL=std: A/B switches for timing runs
     if (use_pp < 0) {
         const char* e = getenv("THEIA_GEMM_KERNEL");
@@ -291,7 +293,13 @@ static int gemm_nt_plan(const theia_gemm_args_t* a, int dtype) {
     }
     const int hkt = dtype == THEIA_FP8 ? 64 : dtype == THEIA_BF16 ? 32 : 16;  // k elements of one half-tile of the ping-pong kernels
     const int esz = dtype == THEIA_FP8 ? 1 : dtype == THEIA_BF16 ? 2 : 4;
-    const bool pp_ok = a->K % hkt == 0 && a->map.in_c % hkt == 0 && (int64_t)a->map.in_c * esz <= 16384;  // one tap's row fits the zero page
+    // what the persistent ping-pong kernel (gemm_pp.hip) takes: half-tile granularity of K and of a tap, one tap's row inside the zero
+    // page, rows addressable by its stepping epilogue (gemm_epi_direct.h), no position row-table, a residual only without activation
+    const bool has_aux = a->act == THEIA_ACT_MUL_DGELU || a->act == THEIA_ACT_MUL_DRELU;
+    const bool pp_ok = a->K % hkt == 0 && a->map.in_c % hkt == 0 && (int64_t)a->map.in_c * esz <= 16384 && a->M < (1 << 24) &&
+                       gd_rows_steppable(a->map) && a->rowtab == nullptr && (a->resid == nullptr || a->act == THEIA_ACT_NONE) &&
+                       (a->ln_sums == nullptr || a->act == THEIA_ACT_NONE || a->act == THEIA_ACT_RELU) &&
+                       (a->tile != 320256 || (dtype == THEIA_BF16 && (a->ln_sums == nullptr || a->map.rows_h * a->map.rows_w >= 160)));
     const bool conv_ok = dtype != THEIA_FP8 && theia_gemm_conv_pp_match(a, dtype, nullptr);
     // The ping-pong kernels' statistics-emitting instantiations carry no residual / aux_in prefetch (with it they spill registers):
     // a launch that wants both -- none of the reference's layers does -- runs on the 2-stage 128x128 kernel.
@@ -301,32 +309,34 @@ static int gemm_nt_plan(const theia_gemm_args_t* a, int dtype) {
             theia_set_error("theia_gemm_nt(fp8): ln_sums together with resid / aux_in is not available");
             return THEIA_ERR_UNSUPPORTED;
         }
-        if (!pp_ok || (a->tile != 0 && a->tile != 256256)) {
+        if (!pp_ok || (a->tile != 0 && a->tile != 256256)) {  // (no 320-row fp8 instantiation)
             theia_set_error("theia_gemm_nt(fp8): needs K and in_c multiples of 64 and the 256x256 ping-pong kernel (K=%d in_c=%d tile=%d)", a->K,
                             a->map.in_c, a->tile);
             return THEIA_ERR_UNSUPPORTED;
         }
         return 256256;
     }
-    if (a->tile == 256256 && !pp_ok) {
-        theia_set_error("theia_gemm_nt: the 256x256 ping-pong kernel needs K and in_c multiples of %d and in_c <= %d (K=%d in_c=%d)", hkt,
-                        dtype == THEIA_BF16 ? 8192 : 4096, a->K, a->map.in_c);
+    if (want_pp && !pp_ok) {
+        theia_set_error("theia_gemm_nt: the ping-pong kernel needs K and in_c multiples of %d, in_c <= %d, no rowtab, a residual only with act "
+                        "NONE, rows it can step through; 320-row tiles are bf16 only (K=%d in_c=%d tile=%d)", hkt,
+                        dtype == THEIA_BF16 ? 8192 : 4096, a->K, a->map.in_c, a->tile);
         return THEIA_ERR_UNSUPPORTED;
     }
     if (a->tile == 256009 && !conv_ok) {
         theia_set_error("theia_gemm_nt: tile request 256009 needs a 3x3 stride-1 convolution row map with one 16x16 image per 256-row tile");
         return THEIA_ERR_UNSUPPORTED;
     }
-    if (sums_and_prefetch && (a->tile == 256009 || a->tile == 256256)) {
+    if (sums_and_prefetch && (a->tile == 256009 || want_pp)) {
         theia_set_error("theia_gemm_nt: ln_sums together with resid / aux_in is not available on the 256x256 ping-pong kernels (tile request %d)", a->tile);
         return THEIA_ERR_UNSUPPORTED;
     }
     if (sums_and_prefetch && tile == 256256) return 128128;
     if (a->tile == 256009) return 256009;
-    if (a->tile == 256256) return 256256;
+    if (want_pp) return theia_gemm_nt_pp_bm(a, dtype) == 320 ? 320256 : 256256;
     if (tile == 256256) {
         if (use_pp && use_conv && conv_ok) return 256009;
-        return use_pp && pp_ok ? 256256 : 256000;
+        if (use_pp && pp_ok) return theia_gemm_nt_pp_bm(a, dtype) == 320 ? 320256 : 256256;
+        return 256000;
     }
     return tile;
 }
@@ -359,7 +369,7 @@ extern "C" int theia_gemm_nt(const theia_gemm_args_t* a, int dtype, void* stream
     const int plan = gemm_nt_plan(a, dtype);
     if (plan < 0) return plan;
     if (plan == 256009) return theia_gemm_conv_pp_launch(a, dtype, s);
-    if (plan == 256256) return theia_gemm_nt_pp_launch(a, dtype, s);
+    if (plan == 256256 || plan == 320256) return theia_gemm_nt_pp_launch(a, dtype, s);
     if (dtype == THEIA_BF16) {
         if (plan == 256000) return launch_gemm_nt<bf16_t, 256, 256, 2, 4>(a, s);
         return plan == 128064 ? launch_gemm_nt<bf16_t, 128, 64, 2, 2>(a, s) : launch_gemm_nt<bf16_t, 128, 128, 2, 2>(a, s);

@@ -1,0 +1,307 @@
+// LDS-free epilogue of the ping-pong GEMM kernels: the accumulators are converted and stored straight from the MFMA layout.
+//
+// gt_epilogue (gemm_tile.h) stages every wave tile through LDS to get 16-byte row-contiguous stores: two staging passes (~1.8k
+// cycles each per 256x256 tile, tools/pp_trace.hip) and -- worse -- an LDS footprint that collides with the operand ring, so the
+// next tile's operands cannot be requested before the epilogue is over.  Here the WEIGHT rows are permuted when they are staged
+// (gd_wperm: LDS row rho of a wave's 64 weight rows holds weight row perm(rho); free, the LDS-DMA source address is per lane), so
+// that the accumulator fragments of one lane cover CONTIGUOUS output columns:
+//     acc[i][j][e]  <->  row m = j*16 + (lane & 15),  column n = (i >> 1)*32 + (lane >> 4)*8 + (i & 1)*4 + e
+// i.e. fragments (2t, 2t+1) of a lane are 8 consecutive columns = one 16-byte bf16 store, and the 4 lanes of a row cover 32
+// consecutive columns (64 B contiguous; the two t halves of a row complete its 128 B).  Bias, activation, residual, statistics
+// are row-local and happen in registers.  No LDS, no lgkmcnt waits, no staging VALU.
+#pragma once
+#include <type_traits>
+#include "gemm_tile.h"
+
+// weight row (within a 64-row wave slice; higher bits pass through) held by LDS row rho
+__device__ __forceinline__ int gd_wperm(int rho) { return (rho & ~31) | ((rho & 12) << 1) | ((rho & 16) >> 2) | (rho & 3); }
+
+template <int I0, int I1, typename F> __device__ __forceinline__ void gd_static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        gd_static_for<I0 + 1, I1>(f);
+    }
+}
+
+// Output-row addressing of a row map, stepped 16 rows at a time (one MFMA fragment row group): decode (image, y, x) once per lane,
+// then add constants (see gt_epilogue for the derivation; RPP = 16 here).  Only maps whose 16-row step wraps at most once in x and
+// once in y (16 / rows_w + 1 <= rows_h) or that have one row per "image" (plain matrices): gd_rows_steppable, checked by the dispatch.
+__host__ __device__ inline bool gd_rows_steppable(const theia_rowmap_t& mp) {
+    return mp.rows_h * mp.rows_w == 1 || 16 / mp.rows_w + 1 <= mp.rows_h;
+}
+struct gd_rows_t {
+    int R, rows_w, rows_h, step_qw, step_rw;
+    bool plain;
+    float rcp_R, rcp_w;
+    int64_t d_step, d_wx, d_wy;
+    struct cursor_t { int m, ry, rx; int64_t off; };
+
+    __device__ __forceinline__ gd_rows_t(const theia_gemm_args_t& p) {
+        const theia_rowmap_t& mp = p.map;
+        R = mp.rows_h * mp.rows_w;
+        rows_w = mp.rows_w;
+        rows_h = mp.rows_h;
+        rcp_R = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.0f / (float)R)));
+        rcp_w = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.0f / (float)mp.rows_w)));
+        step_qw = 16 / mp.rows_w;
+        step_rw = 16 - step_qw * mp.rows_w;
+        plain = R == 1;
+        const int64_t row_pitch = (int64_t)mp.out_sy * mp.out_w * p.ldo;
+        d_step = plain ? (int64_t)16 * mp.out_batch_stride : step_qw * row_pitch + (int64_t)step_rw * mp.out_sx * p.ldo;
+        d_wx = row_pitch - (int64_t)mp.rows_w * mp.out_sx * p.ldo;
+        d_wy = mp.out_batch_stride - mp.rows_h * row_pitch;
+    }
+    __device__ __forceinline__ int64_t decode(const theia_gemm_args_t& p, int m, int& ry, int& rx) const {
+        const theia_rowmap_t& mp = p.map;
+        if (plain) {
+            ry = rx = 0;
+            return (int64_t)m * mp.out_batch_stride + mp.out_offset + (int64_t)(mp.out_y0 * mp.out_w + mp.out_x0) * p.ldo;
+        }
+        int rem;
+        const int img = gt_divmod24(m, R, rcp_R, rem);
+        ry = gt_divmod24(rem, rows_w, rcp_w, rx);
+        return (int64_t)img * mp.out_batch_stride + mp.out_offset +
+               (int64_t)((ry * mp.out_sy + mp.out_y0) * mp.out_w + rx * mp.out_sx + mp.out_x0) * p.ldo;
+    }
+    __device__ __forceinline__ cursor_t first(const theia_gemm_args_t& p, int m) const {
+        cursor_t c;
+        c.m = m;
+        c.off = decode(p, m, c.ry, c.rx);
+        return c;
+    }
+    __device__ __forceinline__ void next(cursor_t& c) const {  // advance by 16 rows
+        c.m += 16;
+        c.off += d_step;
+        if (!plain) {
+            c.rx += step_rw;
+            c.ry += step_qw;
+            const bool wx = c.rx >= rows_w;
+            c.rx -= wx ? rows_w : 0;
+            c.ry += wx ? 1 : 0;
+            c.off += wx ? d_wx : 0;
+            const bool wy = c.ry >= rows_h;
+            c.ry -= wy ? rows_h : 0;
+            c.off += wy ? d_wy : 0;
+        }
+    }
+};
+
+__device__ __forceinline__ void gd_unpack8(const gt_u32x4& u, float (&f)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = __uint_as_float(u[j] << 16);
+        f[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u);
+    }
+}
+
+// one 16-byte row piece, issued as inline asm: invisible to hipcc's waitcnt bookkeeping (the callers wait themselves)
+__device__ __forceinline__ void gd_load16(gt_u32x4& dst, const void* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+
+// state shared by the activation-specialised bodies below
+template <typename T> struct gd_ctx_t {
+    T* O;
+    const T* RES;
+    const T* AUXI;
+    T* AUXO;
+    T* dump;
+    int ncol[2];
+    bool nok[2];
+    float bias8[2][8];
+    float alpha;
+    int64_t off_dead;
+    int m_split;
+    float ls0, lq0, ls1, lq1;
+};
+
+// One wave tile with a fixed activation.  PRE (bf16 only): the aux_in (MUL_D*) / residual rows are prefetched in chunks of CJ row
+// groups with inline-asm loads: chunk c+1 is requested before chunk c's stores are issued and waited for (vmcnt(0): loads and
+// stores share the counter and retire out of order with respect to each other) after them.
+template <typename T, int FM, bool SUMS, bool SCALE, bool BIAS_IN_ACC, int ACT, bool PRE>
+__device__ __forceinline__ void gd_epilogue_body(gt_f32x4 (&acc)[4][FM], const theia_gemm_args_t& p, const gd_rows_t& rw, int m_row0,
+                                                 gd_ctx_t<T>& cx) {
+    constexpr bool WANT_AUX = ACT == THEIA_ACT_MUL_DGELU || ACT == THEIA_ACT_MUL_DRELU;
+    constexpr int CJ = 2, NC = FM / CJ;
+    static_assert(FM % CJ == 0, "row groups are processed in pairs");
+    const T* __restrict__ PREP = WANT_AUX ? cx.AUXI : cx.RES;
+    gd_rows_t::cursor_t cur = rw.first(p, m_row0);
+    gd_rows_t::cursor_t pc = cur;
+    gt_u32x4 rows[2][CJ][2];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int jj = 0; jj < CJ; ++jj) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bool lv = (pc.m < p.M) && cx.nok[t];
+                gd_load16(rows[0][jj][t], PREP + (lv ? pc.off + cx.ncol[t] : cx.off_dead));
+            }
+            rw.next(pc);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int jj = 0; jj < CJ; ++jj)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(rows[0][jj][t]));
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (PRE && c + 1 < NC) {  // rows of the next chunk; dead lanes read row 0 (valid memory)
+#pragma unroll
+            for (int jj = 0; jj < CJ; ++jj) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bool lv = (pc.m < p.M) && cx.nok[t];
+                    gd_load16(rows[(c + 1) & 1][jj][t], PREP + (lv ? pc.off + cx.ncol[t] : cx.off_dead));
+                }
+                rw.next(pc);
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < CJ; ++jj) {
+            const int j = c * CJ + jj;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bool live = (cur.m < p.M) && cx.nok[t];
+                const int64_t o = live ? cur.off + cx.ncol[t] : cx.off_dead;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[2 * t][j][e];
+                    v[4 + e] = acc[2 * t + 1][j][e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if constexpr (SCALE) v[e] *= cx.alpha;
+                    if constexpr (!BIAS_IN_ACC) v[e] += cx.bias8[t][e];
+                }
+                float a8[8];
+                if constexpr (WANT_AUX) {
+                    if constexpr (PRE) gd_unpack8(rows[c & 1][jj][t], a8);
+                    else load8(cx.AUXI + o, a8);
+                }
+                if constexpr (ACT == THEIA_ACT_GELU) {
+                    if (cx.AUXO != nullptr) store8(live ? cx.AUXO + o : cx.dump, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gt_gelu<T>(v[e]);
+                } else if constexpr (ACT == THEIA_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if constexpr (ACT == THEIA_ACT_MUL_DGELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= gt_gelu_grad<T>(a8[e]);
+                } else if constexpr (ACT == THEIA_ACT_MUL_DRELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = a8[e] > 0.f ? v[e] : 0.f;
+                }
+                if (ACT == THEIA_ACT_NONE && cx.RES != nullptr) {  // (the dispatch keeps residual + activation launches off this kernel)
+                    float r8[8];
+                    if constexpr (PRE) gd_unpack8(rows[c & 1][jj][t], r8);
+                    else load8(cx.RES + o, r8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r8[e];
+                }
+                store8(live ? cx.O + o : cx.dump, v);
+                if constexpr (SUMS) {
+                    float s = 0.f, sq = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float r = sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(v[e])) : v[e];  // the value as stored
+                        s += r;
+                        sq += r * r;
+                    }
+                    s = live ? s : 0.f;
+                    sq = live ? sq : 0.f;
+                    const bool first = cur.m < cx.m_split;
+                    cx.ls0 += first ? s : 0.f;
+                    cx.lq0 += first ? sq : 0.f;
+                    cx.ls1 += first ? 0.f : s;
+                    cx.lq1 += first ? 0.f : sq;
+                    // pin the running sums here: left alone, the optimiser sinks the whole reduction behind the last block and keeps
+                    // every block's 8 stored values alive for it (128 registers: scratch spills)
+                    asm volatile("" : "+v"(cx.ls0), "+v"(cx.lq0), "+v"(cx.ls1), "+v"(cx.lq1));
+                }
+            }
+            rw.next(cur);
+        }
+        if (PRE && c + 1 < NC) {  // the next chunk's rows were requested before this chunk's stores: one wait for both
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int jj = 0; jj < CJ; ++jj)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(rows[(c + 1) & 1][jj][t]));
+        }
+    }
+}
+
+// acc: FM x 4 fragments of one wave (rows m_wave0 .. +16*FM, columns n_wave0 .. +64 in the permuted order above).
+// T = output element type.  BIAS_IN_ACC: the kernel initialised the accumulators with the bias row (then it is not added again);
+// resid_in_acc: the same for the residual rows (act == NONE only).  SCALE: fp8 operands, accumulators are rescaled first.
+template <typename T, int FM, bool SUMS, bool SCALE, bool BIAS_IN_ACC>
+__device__ __forceinline__ void gd_epilogue(gt_f32x4 (&acc)[4][FM], const theia_gemm_args_t& p, const gd_rows_t& rw, int m_wave0,
+                                            int n_wave0, int lane, bool resid_in_acc) {
+    const int frow = lane & 15, fg = lane >> 4;
+    gd_ctx_t<T> cx;
+    cx.O = reinterpret_cast<T*>(p.out);
+    cx.RES = resid_in_acc ? nullptr : reinterpret_cast<const T*>(p.resid);
+    cx.AUXI = reinterpret_cast<const T*>(p.aux_in);
+    cx.AUXO = reinterpret_cast<T*>(p.aux_out);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        cx.ncol[t] = n_wave0 + t * 32 + fg * 8;
+        cx.nok[t] = cx.ncol[t] < p.N;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cx.bias8[t][e] = 0.f;
+        if constexpr (!BIAS_IN_ACC) {
+            if (p.bias != nullptr && cx.nok[t]) load8(p.bias + cx.ncol[t], cx.bias8[t]);
+        }
+    }
+    cx.alpha = 1.0f;
+    if constexpr (SCALE) cx.alpha = (p.a_scale_inv != nullptr ? *p.a_scale_inv : 1.0f) * (p.w_scale_inv != nullptr ? *p.w_scale_inv : 1.0f);
+    int dry, drx;
+    cx.off_dead = rw.decode(p, 0, dry, drx);  // where dead lanes (rows >= M, columns >= N) read from: row 0, column 0
+    cx.dump = reinterpret_cast<T*>(g_gt_dump) + lane * 8;
+    // per-image (sum, sum of squares) of the stored values: see gt_epilogue
+    unsigned long long* const lsum = SUMS ? reinterpret_cast<unsigned long long*>(p.ln_sums) : nullptr;
+    int img0 = 0;
+    cx.m_split = 0;
+    if constexpr (SUMS) {
+        int dummy;
+        img0 = gt_divmod24(m_wave0 < p.M ? m_wave0 : 0, rw.R, rw.rcp_R, dummy);
+        cx.m_split = (img0 + 1) * rw.R;
+    }
+    cx.ls0 = cx.lq0 = cx.ls1 = cx.lq1 = 0.f;
+    // the row prefetch costs 32 registers: the 160-row wave tile and the statistics epilogues (whose launches never carry an
+    // aux_in / residual row: the dispatch sends that combination elsewhere) read such rows with plain loads instead
+    constexpr bool CAN_PRE = sizeof(T) == 2 && FM <= 8 && !SUMS;
+    const int m_row0 = m_wave0 + frow;
+    if constexpr (SUMS) {  // the statistics launches are the convolutions in front of a LayerNorm[C,H,W]: no activation or ReLU
+        if (p.act == THEIA_ACT_RELU) gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_RELU, false>(acc, p, rw, m_row0, cx);
+        else gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_NONE, false>(acc, p, rw, m_row0, cx);
+    } else {
+        switch (p.act) {
+            case THEIA_ACT_GELU: gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_GELU, false>(acc, p, rw, m_row0, cx); break;
+            case THEIA_ACT_RELU: gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_RELU, false>(acc, p, rw, m_row0, cx); break;
+            case THEIA_ACT_MUL_DGELU: gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_MUL_DGELU, CAN_PRE>(acc, p, rw, m_row0, cx); break;
+            case THEIA_ACT_MUL_DRELU: gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_MUL_DRELU, CAN_PRE>(acc, p, rw, m_row0, cx); break;
+            default:
+                if (CAN_PRE && cx.RES != nullptr) gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_NONE, CAN_PRE>(acc, p, rw, m_row0, cx);
+                else gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_NONE, false>(acc, p, rw, m_row0, cx);
+                break;
+        }
+    }
+    if constexpr (SUMS) {
+        const float ls0 = wave_sum(cx.ls0), lq0 = wave_sum(cx.lq0), ls1 = wave_sum(cx.ls1), lq1 = wave_sum(cx.lq1);
+        // 2^-24 fixed point in 64-bit integers: integer addition is associative, so the totals do not depend on the order in
+        // which the waves arrive (bit-reproducible steps), and a wave's partial loses < 6e-8 absolute
+        auto fx = [](float v) { return (unsigned long long)__double2ll_rn((double)v * 16777216.0); };
+        if (lane == 0 && m_wave0 < p.M) {
+            atomicAdd(lsum + 2 * img0, fx(ls0));
+            atomicAdd(lsum + 2 * img0 + 1, fx(lq0));
+            if ((int64_t)(img0 + 1) * rw.R < p.M) {  // a second image exists (its sums are zero when the tile did not reach it)
+                atomicAdd(lsum + 2 * (img0 + 1), fx(ls1));
+                atomicAdd(lsum + 2 * (img0 + 1) + 1, fx(lq1));
+            }
+        }
+    }
+}

@@ -1,336 +1,469 @@
-// Ping-pong NT implicit GEMM for the 256x256 tile (8 wave64 = two groups of four, one wave of each group per SIMD).
+// Persistent ping-pong NT implicit GEMM: BM x 256 tiles (BM = 256 or 320), 8 wave64 = two groups of four, one wave of each group
+// per SIMD, ONE workgroup per CU that walks over its tiles.
 //
 // The two wave groups run the same program ONE BARRIER APART, and the program alternates two kinds of segments:
-//     R(P): ds_read_b128 the operand fragments of phase P              |  M(P): 16 x v_mfma_f32_16x16x32_bf16
+//     R(h): ds_read_b128 the operand fragments of half k-tile h          |  M(h): FM*4 x v_mfma_f32_16x16x32_bf16
 // so whenever group 0 is in an M segment group 1 is in an R segment and vice versa: the matrix pipe of every SIMD is fed by
-// one wave while the SIMD's other wave fetches its next fragments (rocprofv3 on the lock-step kernels: 28 % MFMA busy, 42 %
-// of wave cycles parked in s_waitcnt/s_barrier).  Operands arrive by LDS-DMA (global_load_lds_dwordx4) into a 4-deep ring
-// of HALF k-tiles (32 bf16 / 16 f32 of k per row, 64-byte rows, source-side XOR swizzle); the four pieces of half-tile h+3
-// are issued in R(h), right after the fragment reads (an LDS-DMA instruction costs ~60-100 issue cycles: between a group's
-// own MFMAs that is lost matrix-pipe time, in the R segment it overlaps the OTHER group's MFMAs; +5 % measured), and only
-// counted waits are used:
-//     end of R(h):  s_waitcnt vmcnt(8)  -> half-tile h+1 has landed (h+2 and the just-issued h+3 stay in flight)
-// One phase per half-tile: R(h) reads 4 B + 8 A fragments, M(h) issues 32 MFMAs (cycle trace, tools/pp_trace.hip: R is
-// ~720 cycles, M ~630, so the R segment -- 12 ds_read_b128 + 4 LDS-DMA issues -- sets the interval).
+// one wave while the SIMD's other wave fetches its next fragments.  Operands arrive by LDS-DMA (global_load_lds_dwordx4) into a
+// 4-deep ring of HALF k-tiles (32 bf16 / 16 f32 of k per row, 64-byte rows, source-side XOR swizzle); the pieces of half-tile
+// g+3 are issued in R(g), right after the fragment reads, and only counted waits are used:
+//     end of R(g):  s_waitcnt vmcnt(2 * pieces per half-tile)  -> half-tile g+1 has landed (g+2 and the just-issued g+3 in flight)
 //
-// Hazards (interval k = time between barrier k and k+1; group 0 runs segment k in interval k, group 1 segment k-1):
-//   WAR  ring slot (h+3)&3 = (h-1)&3 is refilled from R(h) on (interval >= 2h); its last readers are R(h-1) of group 0
-//        (interval 2h-2) and of group 1 (interval 2h-1), both closed by s_waitcnt lgkmcnt(0) before their barrier.
-//   RAW  half-tile h+1 is first read in interval 2h+2 (group 0, R(h+1)); every wave has waited for its own pieces of it at
-//        the end of its R(h) (interval 2h / 2h+1), i.e. before barrier 2h+2.
+// What round 3 changed, and why (profiles/r02_pp_tile_phases.txt: a K = 768 tile was ~8k cycles of prologue + 35k of loop + 12-23k
+// of epilogue, with nothing overlapping the two ends, and the N = 768 shapes of the ViT ran 297 tiles on 256 CUs = two rounds for
+// 1.16 rounds of work):
+//   * the half-tile stream is CONTINUOUS across a workgroup's tiles: the ring slot is (global half-tile counter) & 3, and the last
+//     three iterations of a tile already request the first three half-tiles of the next one (they used to re-fetch the last
+//     half-tile to keep the counted waits uniform).  The next tile's operands land while the epilogue runs;
+//   * the epilogue is LDS-free (gemm_epi_direct.h: weight rows permuted at staging so that a lane's accumulators are contiguous
+//     output columns) -- nothing in it collides with the ring, and the two LDS staging passes are gone;
+//   * bias and (for act == NONE) the residual rows initialise the accumulators: the residual rows of a workgroup's first tile are
+//     requested before the operand prologue and land behind it (they used to cost 8.5k cycles of the epilogue);
+//   * BM = 320 (wave tile 160 x 64, 160 accumulator registers): 25216 rows = 79 tiles of 320, so the N = 768 launches are ONE
+//     round of 237 tiles instead of two rounds of 256 + 41; 142 instead of 128 flop per L2->LDS byte;
+//   * single-tap row maps (every nn.Linear) run an instantiation without the per-tap gather state (TAPS = false).
+//
+// Hazards (interval k = time between barrier k and k+1; group 0 runs segment k in interval k, group 1 segment k-1), g = global
+// half-tile counter of the workgroup:
+//   WAR  ring slot (g+3)&3 = (g-1)&3 is refilled from R(g) on (interval >= 2g); its last readers are R(g-1) of group 0
+//        (interval 2g-2) and of group 1 (interval 2g-1), both closed by s_waitcnt lgkmcnt(0) before their barrier.  Across a tile
+//        boundary the groups re-synchronise (one extra barrier each side of the epilogue), which only adds distance.
+//   RAW  half-tile g+1 is first read in interval 2g+2 (group 0, R(g+1)); every wave has waited for its own pieces of it at
+//        the end of its R(g), i.e. before barrier 2g+2.  The first half-tile of a later tile: s_waitcnt vmcnt(0) + barrier after
+//        the epilogue (its stores share the counter with the LDS-DMA loads and retire out of order with respect to them, so no
+//        counted wait is valid until they have drained; the epilogue's last stores are acknowledged within a few hundred cycles).
 #include <type_traits>
-#include "gemm_tile.h"
+#include "gemm_epi_direct.h"
 
-// zeros read by out-of-range rows / taps: such a lane's source pointer is the page start and advances with the k offset
+// zeros read by out-of-range taps (multi-tap maps): such a lane's source pointer is the page start and advances with the k offset
 // inside a tap like every other lane's, so the page covers one tap's row (in_c elements <= 16 KiB, checked by the dispatch)
 __device__ uint4 g_pp_zero_page[1024 + 1];
 
-// Ablation switches for tools/pp_trace.hip (timing only, results are wrong): -DPP_EXP_NOMFMA / -DPP_EXP_NODMA / -DPP_EXP_NOLDS
-// drop the MFMAs / the LDS-DMA operand stream / the fragment reads from the main loop.  One round of 255 tiles with
-// K = 6912 (255 CUs busy): everything 220 us, LDS-DMA only 172 us, MFMA only 121 us, and LDS-DMA only on 24 CUs 120 us --
-// the L2 -> LDS operand stream (32 KiB per CU per half-tile, ~10 TB/s over the chip at most, 64- or 128-byte rows alike),
-// not the matrix pipe, bounds this kernel at full occupancy.
-// Optional cycle trace (tools/pp_trace.hip builds this file with -DPP_TRACE): s_memtime stamps of block 0 at the segment
-// boundaries of iterations PP_TRACE_H0 .. PP_TRACE_H0+3, one row per wave.  Compiled out of the library.
+// Optional cycle stamps (tools/pp_bench.hip builds this file with -DPP_TRACE): block 0 and the block that runs tile 1 of CU 0
 #ifdef PP_TRACE
-__device__ unsigned long long g_pp_trace[8][4][2][5];
-__device__ unsigned long long g_pp_phase[2][8][7];
-#define PP_PHASE(k)                                                                  \
-    if ((blockIdx.x & 255) == 0 && blockIdx.x < 512 && (threadIdx.x & 63) == 0)      \
-        g_pp_phase[blockIdx.x >> 8][threadIdx.x >> 6][k] = __builtin_readcyclecounter();
-#define PP_STAMP(k)                                                                                  \
-    if (blockIdx.x == 0 && h >= PP_TRACE_H0 && h < PP_TRACE_H0 + 4 && lane == 0)                      \
-        g_pp_trace[wave][h - PP_TRACE_H0][0][k] = __builtin_readcyclecounter();
-#define PP_STAMP2(k)                                                                                 \
-    if (blockIdx.x == 0 && h >= PP_TRACE_H0 && h < PP_TRACE_H0 + 4 && lane == 0)                      \
-        g_pp_trace[wave][h - PP_TRACE_H0][1][k] = __builtin_readcyclecounter();
+__device__ unsigned long long g_pp_phase[8][16];
+#define PP_PHASE(k) \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (k) < 16) g_pp_phase[threadIdx.x >> 6][k] = __builtin_readcyclecounter();
 #else
-#define PP_STAMP(k)
-#define PP_STAMP2(k)
 #define PP_PHASE(k)
 #endif
 
 __device__ __forceinline__ int pp_f(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
-// CXXR: A/B switch (THEIA_PP_READS=cxx) -- fragment reads as plain C++ LDS loads, the form in which hipcc puts `s_waitcnt vmcnt(0)`
-// in front of them (every LDS-DMA in flight is drained at the top of each iteration)
-template <typename T, bool CXXR = false, bool SUMS = false>
-__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t p) {
-    constexpr int BM = 256, BN = 256, WAVES_N = 4;
+template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// T: operand type.  BM: tile rows.  TAPS: multi-tap (3x3 gather) row maps; false = single-tap maps only.  SUMS: ln_sums epilogue.
+template <typename T, int BM, bool TAPS, bool SUMS>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t p, const int ntiles) {
+    constexpr int BN = 256, WAVES_N = 4;
     constexpr int NSTAGE = 4;
     constexpr int HKT = 64 / (int)sizeof(T);
     constexpr int EPC = 16 / (int)sizeof(T);
-    constexpr int WM = 128, WN = 64, FM = 8, FN = 4;
-    constexpr int SRP = 128;                    // rows staged per pass (512 threads x 16 B = 128 rows of 64 B)
-    constexpr int NPA = BM / SRP, NPB = BN / SRP;
-    constexpr int LPH = NPA + NPB;              // 4 LDS-DMA pieces per thread per half-tile
+    constexpr int WM = BM / 2, WN = 64, FM = WM / 16, FN = 4;
+    constexpr int SRP = 128;                      // rows staged per pass (512 threads x 16 B = 128 rows of 64 B)
+    constexpr int NPA = (BM + SRP - 1) / SRP;      // A passes; the last one covers BM % 128 rows when BM is not a multiple of 128
+    constexpr int A_TAIL_WAVES = (BM % SRP) / 16;  // waves that take part in the partial A pass (0 = every pass is full)
+    constexpr int NPB = BN / SRP;
+    constexpr int LPH_FULL = NPA + NPB;            // pieces per half-tile of a wave that takes part in every pass
+    constexpr int LPH_PART = LPH_FULL - (A_TAIL_WAVES ? 1 : 0);
     constexpr int STAGE = (BM + BN) * 64;
-    static_assert(LPH == 4, "the counted waits assume 4 pieces per thread per half-tile");
+    constexpr bool SCALE = sizeof(T) == 1;
+    constexpr bool BIAS_IN_ACC = !SCALE;
+    using OutT = typename std::conditional<sizeof(T) == 1, bf16_t, T>::type;  // fp8 operands: bf16 out, accumulators rescaled
+    static_assert(BM % 32 == 0 && WM % 32 == 0, "two wave groups of whole fragment pairs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int uwave = __builtin_amdgcn_readfirstlane(wave);
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;  // wm = wave group (0: waves 0-3, 1: waves 4-7)
+    const int uwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ugroup = uwave >> 2;
+    const int wm = ugroup, wn = uwave & (WAVES_N - 1);  // wm = wave group (0: waves 0-3, 1: waves 4-7); scalars
+    const bool tailw = A_TAIL_WAVES == 0 || uwave < A_TAIL_WAVES;  // this wave issues the partial A pass
     const theia_rowmap_t& mp = p.map;
     const int tiles_n = (p.N + BN - 1) / BN;
     PP_PHASE(0)
-    const int tile = gt_xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    // tiles of this workgroup: round r of the grid takes tiles [r * grid, r * grid + cnt), spread over the XCDs like a launch of cnt
+    const int grid = gridDim.x, bid = blockIdx.x;
+    const int rounds = (ntiles + grid - 1) / grid;
+    const int cnt_last = ntiles - (rounds - 1) * grid;
+    const int my_tiles = rounds - 1 + (bid < cnt_last ? 1 : 0);
+    auto tile_of = [&](int r) { return r * grid + gt_xcd_remap(bid, r + 1 < rounds ? grid : cnt_last); };
     const T* __restrict__ A = reinterpret_cast<const T*>(p.a);
     const T* __restrict__ W = reinterpret_cast<const T*>(p.w);
-
-    const int st_chunk = tid & 3, st_row = tid >> 2;
-    const int lchunk = st_chunk ^ pp_f(st_row);
     const int R = mp.rows_h * mp.rows_w;
-    const float rcp_R = 1.0f / (float)R, rcp_w = 1.0f / (float)mp.rows_w;
-    int64_t a_base[NPA];
-    int a_iy0[NPA], a_ix0[NPA];
-#pragma unroll
-    for (int i = 0; i < NPA; ++i) {
-        const int m = m0 + st_row + SRP * i;
-        if (m < p.M) {
-            int rem, rx;
-            const int img = gt_divmod(m, R, rcp_R, rem);
-            const int ry = gt_divmod(rem, mp.rows_w, rcp_w, rx);
-            a_base[i] = (int64_t)img * mp.in_batch_stride + mp.in_offset;
-            a_iy0[i] = ry * mp.in_sy;
-            a_ix0[i] = rx * mp.in_sx;
-        } else {
-            a_base[i] = 0;
-            a_iy0[i] = -(1 << 28);
-            a_ix0[i] = 0;
-        }
-    }
-    int64_t w_base[NPB];
-    bool w_ok[NPB];
-#pragma unroll
-    for (int i = 0; i < NPB; ++i) {
-        const int n = n0 + st_row + SRP * i;
-        w_ok[i] = n < p.N;
-        w_base[i] = (int64_t)n * p.ldw;
-    }
-
-    gt_f32x4 acc[FN][FM];  // zeroed below, behind the prologue's LDS-DMA issues (128 v_mov per wave: hidden in the operands' latency)
-
     const int nh = (p.K + HKT - 1) / HKT;   // host guarantees K % HKT == 0 for this kernel
+    const int hpt = mp.in_c / HKT;          // half-tiles per tap
     const uint64_t zp = reinterpret_cast<uint64_t>(g_pp_zero_page);
-    // Per-tap source pointers of this thread's LDS-DMA pieces (recomputed only when the prefetch stream enters a new tap, a
-    // wave-uniform event): inside the M segments a piece costs one masked 64-bit add + the LDS-DMA issue.
-    uint64_t src_ptr[LPH];
+
+    // ---------------------------------------------------------------- operand prefetch stream
+    // State: the tile (round pf_r) and half-tile pf_h that the NEXT issue fetches, this thread's source pointers for that tile
+    // (TAPS: for the current tap, recomputed when the stream enters a new tap), all wave-uniform except the pointers.
+    uint64_t src_ptr[LPH_FULL];
+    int pf_r = 0, pf_h = 0, cur_tap = 0, next_tap_h = hpt, pf_m0 = 0, pf_n0 = 0;
+    // source pointers of tile (pf_m0, pf_n0) for tap `tap`.  Multi-tap maps: out-of-range taps read the zero page; the row decode is
+    // redone at every tap switch (once per in_c / HKT half-tiles) rather than carried in registers across the whole kernel.
+    // Single-tap maps (TAPS = false): rows beyond M / N are clamped to the last row (their products land in rows / columns that are
+    // never stored), so no zero page.
     auto set_tap = [&](int tap) {
+        // lane constants and reciprocals are re-derived HERE from an opaque copy of the thread index / row counts: hoisted to the top
+        // of the kernel they are registers alive across the main loop, which has none to spare at BM = 320
+        int tid_ = threadIdx.x, R_ = R, rows_w_ = mp.rows_w;
+        asm volatile("" : "+v"(tid_));
+        asm volatile("" : "+s"(R_), "+s"(rows_w_));
+        const int st_chunk = tid_ & 3, st_row = tid_ >> 2;
+        const int lchunk = st_chunk ^ pp_f(st_row);
+        const float rcp_R = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.0f / (float)R_)));
+        const float rcp_w = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.0f / (float)rows_w_)));
         const int dy = mp.dy[tap], dx = mp.dx[tap];
         const int64_t wcol = (int64_t)mp.wslot[tap] * mp.in_c + lchunk * EPC;
 #pragma unroll
-        for (int q = 0; q < NPA; ++q) {
-            const int iy = a_iy0[q] + dy, ix = a_ix0[q] + dx;
-            const bool ok = (iy >= 0) & (iy < mp.in_h) & (ix >= 0) & (ix < mp.in_w);
-            const uint64_t pa = reinterpret_cast<uint64_t>(A + a_base[q] + (int64_t)(iy * mp.in_w + ix) * mp.in_c + lchunk * EPC);
-            const uint64_t msk = 0ull - (uint64_t)ok;
-            src_ptr[q] = (pa & msk) | (zp & ~msk);
+        for (int i = 0; i < NPA; ++i) {
+            int m = pf_m0 + st_row + SRP * i;
+            bool ok = true;
+            if constexpr (TAPS) ok = m < p.M;
+            m = min(m, p.M - 1);
+            int64_t off;
+            if (!TAPS && R == 1) {
+                off = (int64_t)m * mp.in_batch_stride + mp.in_offset;
+            } else {
+                int rem, rx;
+                const int img = gt_divmod24(m, R_, rcp_R, rem);
+                const int ry = gt_divmod24(rem, rows_w_, rcp_w, rx);
+                const int iy = ry * mp.in_sy + dy, ix = rx * mp.in_sx + dx;
+                if constexpr (TAPS) ok = ok & (iy >= 0) & (iy < mp.in_h) & (ix >= 0) & (ix < mp.in_w);
+                off = (int64_t)img * mp.in_batch_stride + mp.in_offset + (int64_t)(iy * mp.in_w + ix) * mp.in_c;
+            }
+            const uint64_t pa = reinterpret_cast<uint64_t>(A + off + lchunk * EPC);
+            if constexpr (TAPS) {
+                const uint64_t msk = 0ull - (uint64_t)ok;
+                src_ptr[i] = (pa & msk) | (zp & ~msk);
+            } else {
+                src_ptr[i] = pa;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NPB; ++i) {
-            const uint64_t pw = reinterpret_cast<uint64_t>(W + w_base[i] + wcol);
-            const uint64_t msk = 0ull - (uint64_t)w_ok[i];
-            src_ptr[NPA + i] = (pw & msk) | (zp & ~msk);
+            int n = pf_n0 + gd_wperm(st_row + SRP * i);
+            const bool ok = n < p.N;
+            n = min(n, p.N - 1);
+            const uint64_t pw = reinterpret_cast<uint64_t>(W + (int64_t)n * p.ldw + wcol);
+            if constexpr (TAPS) {
+                const uint64_t msk = 0ull - (uint64_t)ok;
+                src_ptr[NPA + i] = (pw & msk) | (zp & ~msk);
+            } else {
+                src_ptr[NPA + i] = pw;
+            }
         }
     };
-    auto issue_piece = [&](int q, uint64_t coff, char* sa, char* sb) {
-        const uint64_t src = src_ptr[q] + coff;
-        char* dst = q < NPA ? sa + q * (SRP * 64) : sb + (q - NPA) * (SRP * 64);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    auto setup_tile = [&](int tile) {
+        pf_m0 = (tile / tiles_n) * BM;
+        pf_n0 = (tile % tiles_n) * BN;
+        cur_tap = 0;
+        next_tap_h = hpt;
+        set_tap(0);
     };
-    const int hpt = mp.in_c / HKT;  // half-tiles per tap
-    PP_PHASE(1)
-    int cur_tap = 0, next_tap_h = hpt;  // prefetch stream state: tap of half-tile hp, first half-tile of the next tap
-    set_tap(0);
-    // prologue: half-tiles 0..2 (clamped for very short K; the duplicates are never read)
+    // issue the pieces of half-tile (pf_r, pf_h) into ring slot `slot`, then advance the stream.  Past the workgroup's last
+    // half-tile the last one is fetched again (never read; keeps the counted waits uniform)
+    // src_ptr[] always points at half-tile pf_h (inside its tap) and is advanced by one 64-byte row chunk per issue -- ONE live copy of
+    // each pointer (a base + offset form made the compiler carry an incrementing copy next to the base through the loop).
+    auto pf_issue = [&](auto CROSS_C, int slot) {
+        if constexpr (decltype(CROSS_C)::value) {  // this fetch may belong to the next tile
+            if (pf_h == nh) {  // wave-uniform
+                if (pf_r + 1 < my_tiles) {
+                    ++pf_r;
+                    pf_h = 0;
+                    setup_tile(tile_of(pf_r));
+                } else {  // past the workgroup's last half-tile: fetch it again (never read; keeps the counted waits uniform)
+                    pf_h = nh - 1;
 #pragma unroll
-    for (int h = 0; h < NSTAGE - 1; ++h) {
-        const int hp = min(h, nh - 1);
-        if (hp >= next_tap_h) {
-            ++cur_tap;
-            next_tap_h += hpt;
-            set_tap(cur_tap);
+                    for (int q = 0; q < LPH_FULL; ++q) src_ptr[q] -= 64;
+                }
+            }
         }
-        const uint64_t coff = (uint64_t)(hp - cur_tap * hpt) * 64;
-        char* sa = smem + h * STAGE + uwave * (16 * 64);
-#pragma unroll
-        for (int q = 0; q < LPH; ++q) issue_piece(q, coff, sa, sa + BM * 64);
-    }
-    PP_PHASE(2)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-            acc[i][j] = (gt_f32x4){0.f, 0.f, 0.f, 0.f};
-            asm volatile("" : "+v"(acc[i][j]));  // materialise the zeros HERE (the compiler otherwise sinks them behind the wait)
+        if constexpr (TAPS) {
+            if (pf_h >= next_tap_h) {
+                ++cur_tap;
+                next_tap_h += hpt;
+                set_tap(cur_tap);
+            }
         }
+        char* sa = smem + slot * STAGE + uwave * (16 * 64);
+        char* sb = sa + BM * 64;
+#pragma unroll
+        for (int q = 0; q < LPH_FULL; ++q) {
+            if (A_TAIL_WAVES != 0 && q == NPA - 1 && !tailw) continue;  // wave-uniform
+            char* dst = q < NPA ? sa + q * (SRP * 64) : sb + (q - NPA) * (SRP * 64);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_ptr[q],
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            src_ptr[q] += 64;
+        }
+        ++pf_h;
+    };
+    // wait until at most `halves` half-tiles' worth of this wave's pieces are outstanding
+    auto wait_halves2 = [&]() {
+        if (A_TAIL_WAVES != 0 && !tailw) pp_wait_vm<2 * LPH_PART>();
+        else pp_wait_vm<2 * LPH_FULL>();
+    };
+
+    // ---------------------------------------------------------------- accumulator initialisation: bias (+ residual) rows
+    const OutT* __restrict__ RES = reinterpret_cast<const OutT*>(p.resid);
+    const bool want_aux = p.act == THEIA_ACT_MUL_DGELU || p.act == THEIA_ACT_MUL_DRELU;
+    // the residual rows can start the accumulation when nothing sits between the product and the addition (bf16 rows only)
+    const bool resid_init = BIAS_IN_ACC && sizeof(OutT) == 2 && RES != nullptr && p.act == THEIA_ACT_NONE;
+    gt_f32x4 acc[FN][FM];
+    // Starts a tile: requests the bias row and (resid_init) the residual rows of the wave tile, waits, and initialises the
+    // accumulators with them.  FIRST: the workgroup's first tile -- the rows are requested BEFORE the operand prologue (loads retire
+    // in order: they have landed once only the prologue's pieces are outstanding); later tiles: after the previous epilogue, whose
+    // stores share the counter, so everything is drained (the next tile's first half-tiles have been in flight since the last
+    // iterations of the previous tile).  The row registers live only inside this function.
+    auto start_tile = [&](auto FIRST_C, int tile_id, int m_wave0, int n_wave0) {
+        constexpr bool FIRST = decltype(FIRST_C)::value;
+        const int frow = threadIdx.x & 15, fg = (threadIdx.x >> 4) & 3;
+        gt_u32x4 brow[2][2];  // bias: 2 column groups x 8 floats
+        const bool has_bias = BIAS_IN_ACC && p.bias != nullptr;
+        if constexpr (BIAS_IN_ACC) {
+            if (has_bias) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int n = n_wave0 + t * 32 + fg * 8;
+                    const float* bp = p.bias + (n < p.N ? n : 0);
+                    gd_load16(brow[t][0], bp);
+                    gd_load16(brow[t][1], bp + 4);
+                }
+            }
+            if (resid_init) {
+                const gd_rows_t rw(p);
+                int dry, drx;
+                const int64_t off_dead = rw.decode(p, 0, dry, drx);
+                gd_rows_t::cursor_t c = rw.first(p, m_wave0 + frow);
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int n = n_wave0 + t * 32 + fg * 8;
+                        const bool lv = (c.m < p.M) && (n < p.N);
+                        // straight into the accumulator registers of fragment (2t, j): 8 bf16 = 4 dwords, expanded in place below
+                        // (a separate row buffer would be 16 * FM more registers alive next to the full accumulator set)
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(acc[2 * t][j]) : "v"(RES + (lv ? c.off + n : off_dead)) : "memory");
+                    }
+                    rw.next(c);
+                }
+            }
+        }
+        if constexpr (FIRST) {
+            setup_tile(tile_id);
+            PP_PHASE(1)
+#pragma unroll
+            for (int s = 0; s < NSTAGE - 1; ++s) pf_issue(std::true_type{}, s);
+            PP_PHASE(2)
+            __builtin_amdgcn_sched_barrier(0);
+            if (A_TAIL_WAVES != 0 && !tailw) pp_wait_vm<3 * LPH_PART>();
+            else pp_wait_vm<3 * LPH_FULL>();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr (BIAS_IN_ACC) {
+            float b8[2][8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bool ok = has_bias && (n_wave0 + t * 32 + fg * 8) < p.N;
+                if (has_bias) {
+                    asm volatile("" : "+v"(brow[t][0]));
+                    asm volatile("" : "+v"(brow[t][1]));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        b8[t][e] = ok ? __uint_as_float(brow[t][0][e]) : 0.f;
+                        b8[t][4 + e] = ok ? __uint_as_float(brow[t][1][e]) : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) b8[t][e] = 0.f;
+                }
+            }
+            if (resid_init) {
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        asm volatile("" : "+v"(acc[2 * t][j]));  // (use stays behind the wait above)
+                        const gt_u32x4 raw = __builtin_bit_cast(gt_u32x4, acc[2 * t][j]);
+                        float r8[8];
+                        gd_unpack8(raw, r8);
+                        acc[2 * t][j] = (gt_f32x4){b8[t][0] + r8[0], b8[t][1] + r8[1], b8[t][2] + r8[2], b8[t][3] + r8[3]};
+                        acc[2 * t + 1][j] = (gt_f32x4){b8[t][4] + r8[4], b8[t][5] + r8[5], b8[t][6] + r8[6], b8[t][7] + r8[7]};
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        acc[2 * t][j] = (gt_f32x4){b8[t][0], b8[t][1], b8[t][2], b8[t][3]};
+                        acc[2 * t + 1][j] = (gt_f32x4){b8[t][4], b8[t][5], b8[t][6], b8[t][7]};
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) acc[i][j] = (gt_f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) asm volatile("" : "+v"(acc[i][j]));  // materialise HERE (not sunk behind the next wait)
+    };
+
+    // ---------------------------------------------------------------- first tile: init rows, then the operand prologue
+    int tile = tile_of(0);
+    int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    start_tile(std::true_type{}, tile, m0 + wm * WM, n0 + wn * WN);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPH) : "memory");  // half-tile 0 landed
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (ugroup == 1) {  // group 1 runs one barrier behind group 0
+    wait_halves2();  // half-tile 0 landed
+
+    gt_u32x4 fb[FN], fa[FM];
+    int g = 0;  // global half-tile counter of this workgroup: ring slot = g & 3
+
+    for (int r = 0; r < my_tiles; ++r) {
+        // Fragment addresses: rows 16 apart share the swizzle (pp_f looks at bits 2..3 of the row), so the FM A fragments / 4 B
+        // fragments of a wave are 1 KiB apart: one lane-dependent offset each + immediates.  The reads are inline asm (see
+        // gt_ds_read128: a C++ load here would make the compiler drain every in-flight LDS-DMA at the top of each iteration).
+        // Recomputed per tile so that they do not occupy registers during the epilogue.
+        const uint32_t smem_base = gt_lds_addr(smem);
+        const int frow_ = threadIdx.x & 15, fg_ = (threadIdx.x >> 4) & 3;
+        const uint32_t lane_a = smem_base + (wm * WM + frow_) * 64 + ((fg_ ^ pp_f(frow_)) << 4);
+        const uint32_t lane_b = smem_base + BM * 64 + (wn * WN + frow_) * 64 + ((fg_ ^ pp_f(frow_)) << 4);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-    }
-
-    PP_PHASE(3)
-    const int frow = lane & 15, fg = lane >> 4;
-    // Fragment addresses: rows 16 apart share the swizzle (pp_f looks at bits 2..3 of the row), so the 8 A fragments / 4 B
-    // fragments of a wave are 1 KiB apart: one lane-dependent offset each + immediates.  The reads are inline asm (see
-    // gt_ds_read128: a C++ load here would make the compiler drain every in-flight LDS-DMA at the top of each iteration).
-    const uint32_t smem_base = gt_lds_addr(smem);
-    const uint32_t lane_a = smem_base + (wm * WM + frow) * 64 + ((fg ^ pp_f(frow)) << 4);
-    const uint32_t lane_b = smem_base + BM * 64 + (wn * WN + frow) * 64 + ((fg ^ pp_f(frow)) << 4);
-    gt_u32x4 fb[FN], fa[FM];
-#ifdef PP_EXP_NOLDS
-    for (int j = 0; j < FM; ++j) fa[j] = (gt_u32x4){(unsigned)tid, (unsigned)tid, (unsigned)tid, (unsigned)tid};
-    for (int i = 0; i < FN; ++i) fb[i] = (gt_u32x4){(unsigned)tid, (unsigned)tid, (unsigned)tid, (unsigned)tid};
-#endif
-    for (int h = 0; h < nh; ++h) {
-        const int hp = min(h + NSTAGE - 1, nh - 1);  // half-tile prefetched during this iteration (clamped at the tail)
-        if (hp >= next_tap_h) {                       // wave-uniform, once per in_c/HKT iterations
-            ++cur_tap;
-            next_tap_h += hpt;
-            set_tap(cur_tap);
+        if (ugroup == 1) {  // group 1 runs one barrier behind group 0
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
-        const uint64_t coff = (uint64_t)(hp - cur_tap * hpt) * 64;
-        char* na = smem + ((h + NSTAGE - 1) & (NSTAGE - 1)) * STAGE + uwave * (16 * 64);
-        char* nb = na + BM * 64;
-        const uint32_t soff = (uint32_t)(h & (NSTAGE - 1)) * STAGE;
-        {
-            // ---------------- R(h): 12 fragment reads + the 4 LDS-DMA pieces of half-tile h+3
-            PP_STAMP(0)
-#ifndef PP_EXP_NOLDS
+        PP_PHASE(3 + 4 * r)
+        auto half_tile = [&](auto CROSS_C) {
+            const uint32_t soff = (uint32_t)(g & (NSTAGE - 1)) * STAGE;
+            // ---------------- R(g): FN + FM fragment reads + the LDS-DMA pieces of half-tile g+3
             const uint32_t ab = lane_b + soff, aa = lane_a + soff;
-            if constexpr (CXXR) {
+            gd_static_for<0, FN>([&](auto I) { gt_ds_read128<decltype(I)::value * 1024>(fb[decltype(I)::value], ab); });
+            gd_static_for<0, FM>([&](auto J) { gt_ds_read128<decltype(J)::value * 1024>(fa[decltype(J)::value], aa); });
+            pf_issue(CROSS_C, (g + NSTAGE - 1) & (NSTAGE - 1));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int i = 0; i < FN; ++i) fb[i] = *reinterpret_cast<const gt_u32x4*>(smem + (ab - smem_base) + i * 1024);
+            for (int i = 0; i < FN; ++i) asm volatile("" : "+v"(fb[i]));
 #pragma unroll
-                for (int j = 0; j < FM; ++j) fa[j] = *reinterpret_cast<const gt_u32x4*>(smem + (aa - smem_base) + j * 1024);
-            } else {
-            gt_ds_read128<0>(fb[0], ab);
-            gt_ds_read128<1024>(fb[1], ab);
-            gt_ds_read128<2048>(fb[2], ab);
-            gt_ds_read128<3072>(fb[3], ab);
-            gt_ds_read128<0>(fa[0], aa);
-            gt_ds_read128<1024>(fa[1], aa);
-            gt_ds_read128<2048>(fa[2], aa);
-            gt_ds_read128<3072>(fa[3], aa);
-            gt_ds_read128<4096>(fa[4], aa);
-            gt_ds_read128<5120>(fa[5], aa);
-            gt_ds_read128<6144>(fa[6], aa);
-            gt_ds_read128<7168>(fa[7], aa);
-            }
-#endif
-            PP_STAMP2(0)
-#ifndef PP_GLDS_IN_M  // default: the LDS-DMA pieces are issued in the R segment (their ~60-100 issue cycles each overlap the
-                      // OTHER group's MFMAs); -DPP_GLDS_IN_M puts them between this group's MFMAs (5% slower, 2 A/B runs)
-#ifndef PP_EXP_NODMA
-#pragma unroll
-            for (int q = 0; q < LPH; ++q) issue_piece(q, coff, na, nb);
-#endif
-            PP_STAMP2(1)
-            gt_wait_lds(fb, fa);
-            PP_STAMP(1)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPH) : "memory");  // half-tile h+1 landed; h+2, h+3 may be in flight
-#else
-            gt_wait_lds(fb, fa);
-            PP_STAMP(1)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPH) : "memory");  // half-tile h+1 landed; h+2 may still be in flight
-#endif
+            for (int j = 0; j < FM; ++j) asm volatile("" : "+v"(fa[j]));
+            wait_halves2();  // half-tile g+1 landed; g+2, g+3 may be in flight
             __builtin_amdgcn_sched_barrier(0);
-            PP_STAMP(2)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            // ---------------- M(h): 32 MFMAs
-            PP_STAMP(3)
+            // ---------------- M(g): FM * FN MFMAs
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
 #pragma unroll
-#ifdef PP_EXP_NOMFMA
-                for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(fb[i]), "v"(fa[j]));
-#else
                 for (int i = 0; i < FN; ++i) gt_mma<T>(acc[i][j], fb[i], fa[j]);
-#endif
-#ifdef PP_GLDS_IN_M
-                if ((j & 1) == 0) issue_piece(j >> 1, coff, na, nb);
-#endif
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            PP_STAMP(4)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+                };
+        // While h + 3 < nh the fetched half-tile belongs to this tile: the steady loop carries no tile-switch code (inlined into
+        // it, the address set-up of the next tile cost registers -- scratch traffic, whose waits drain the LDS-DMA queue).
+        int h = 0;
+        for (; h + NSTAGE - 1 < nh; ++h, ++g) half_tile(std::false_type{});
+        for (; h < nh; ++h, ++g) half_tile(std::true_type{});
+        if (ugroup == 0) {  // re-join the groups
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
+        PP_PHASE(4 + 4 * r)
+        {
+            const gd_rows_t rw(p);
+            gd_epilogue<OutT, FM, SUMS, SCALE, BIAS_IN_ACC>(acc, p, rw, m0 + wm * WM, n0 + wn * WN, threadIdx.x & 63, resid_init);
+        }
+        PP_PHASE(5 + 4 * r)
+        if (r + 1 < my_tiles) {
+            tile = tile_of(r + 1);
+            m0 = (tile / tiles_n) * BM;
+            n0 = (tile % tiles_n) * BN;
+            start_tile(std::false_type{}, tile, m0 + wm * WM, n0 + wn * WN);
+        }
+        PP_PHASE(6 + 4 * r)
     }
-    if (ugroup == 0) {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), as a builtin so that the compiler KNOWS no LDS-DMA is pending in the epilogue  // drain the clamped tail prefetches before LDS is reused
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail fetches write LDS: let them land before the workgroup exits
+}
 
-    PP_PHASE(4)
-    float* ep = reinterpret_cast<float*>(smem) + wave * (64 * (WN + 4));
-    using OutT = typename std::conditional<sizeof(T) == 1, bf16_t, T>::type;  // fp8 operands: bf16 out, accumulators rescaled
-    const bool prefetch = sizeof(OutT) == 2 && (p.resid != nullptr || p.act == THEIA_ACT_MUL_DGELU || p.act == THEIA_ACT_MUL_DRELU);
-    // (the statistics-emitting instantiation keeps ONE epilogue that decides at run time: with two the register allocation of its
-    // main loop spills -- the stride-2 transposed convolutions ran 2x slower)
-    if constexpr (SUMS) gt_epilogue<OutT, WM, WN, true, sizeof(T) == 1, 4, 0>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
-    else if (prefetch) gt_epilogue<OutT, WM, WN, false, sizeof(T) == 1, 4, 1>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
-    else gt_epilogue<OutT, WM, WN, false, sizeof(T) == 1, 4, 0>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
-    PP_PHASE(5)
-#ifdef PP_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    PP_PHASE(6)
+// ---------------------------------------------------------------------------------------------------------------- launch
+int g_pp_grid_cap = 0;  // > 0: cap on the persistent grid (tools/pp_bench.hip: forces several tiles per workgroup on small problems)
+static int pp_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        const char* e = getenv("THEIA_PP_GRID");  // timing experiments: cap (or, with a huge value, lift) the persistent grid
+        if (e != nullptr && atoi(e) > 0) v = atoi(e);
+        n = v;
+    }
+    return g_pp_grid_cap > 0 ? g_pp_grid_cap : n;
+}
+
+template <typename T, int BM, bool TAPS, bool SUMS>
+static int pp_launch_one(const theia_gemm_args_t* a, hipStream_t stream) {
+    constexpr int lds = 4 * (BM + 256) * 64;
+    auto kern = gemm_nt_pp_kernel<T, BM, TAPS, SUMS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int tiles = cdiv_i(a->M, BM) * cdiv_i(a->N, 256);
+    const int grid = tiles < pp_num_cus() ? tiles : pp_num_cus();
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, *a, tiles);
+    THEIA_CHECK_LAUNCH("theia_gemm_nt(pp)");
+    return THEIA_OK;
+}
+
+// Rows per tile for a launch the ping-pong kernel takes: 320 when that saves whole rounds of the persistent grid (cost of a
+// round ~ rows per tile), else 256.  bf16 only; ln_sums needs a wave tile (160 rows) inside two images.
+int theia_gemm_nt_pp_bm(const theia_gemm_args_t* a, int dtype) {
+    if (a->tile == 320256) return 320;
+    if (a->tile == 256256) return 256;
+    if (dtype != THEIA_BF16) return 256;
+    if (a->ln_sums != nullptr && a->map.rows_h * a->map.rows_w < 160) return 256;
+    static int force = -1;
+    if (force < 0) {
+        const char* e = getenv("THEIA_PP_BM");
+        force = e == nullptr ? 0 : atoi(e);
+    }
+    if (force == 256 || force == 320) return force;
+    const int cus = pp_num_cus(), tn = cdiv_i(a->N, 256);
+    const double c256 = (double)cdiv_i((long)cdiv_i(a->M, 256) * tn, cus) * 256.0;
+    const double c320 = (double)cdiv_i((long)cdiv_i(a->M, 320) * tn, cus) * 320.0;
+    return c320 < c256 ? 320 : 256;
 }
 
 int theia_gemm_nt_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t stream) {
-    constexpr int stage_bytes = 4 * (256 + 256) * 64;
-    constexpr int ep_bytes = 8 * 64 * (64 + 4) * 4;
-    constexpr int lds = stage_bytes > ep_bytes ? stage_bytes : ep_bytes;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+    // the single-tap instantiation clamps rows instead of reading zeros: only for maps whose one tap never leaves the input
+    const theia_rowmap_t& mp = a->map;
+    const bool taps = mp.ntaps > 1 || mp.dy[0] != 0 || mp.dx[0] != 0 || (mp.rows_h - 1) * mp.in_sy >= mp.in_h || (mp.rows_w - 1) * mp.in_sx >= mp.in_w;
+    const bool sums = a->ln_sums != nullptr;
+#ifdef PP_ONE  // compile-time experiments: exactly one instantiation, e.g. -DPP_ONE="bf16_t, 256, true, true"
+    return pp_launch_one<PP_ONE>(a, stream);
+#else
+#ifndef PP_QUICK  // -DPP_QUICK: only the two bf16 single-tap instantiations
+    if (dtype == THEIA_FP8) return sums ? pp_launch_one<fp8_t, 256, true, true>(a, stream) : pp_launch_one<fp8_t, 256, true, false>(a, stream);
+    if (dtype == THEIA_F32) return sums ? pp_launch_one<float, 256, true, true>(a, stream) : pp_launch_one<float, 256, true, false>(a, stream);
+#endif
+    const int bm = theia_gemm_nt_pp_bm(a, dtype);
+    if (bm == 320) {
+#ifndef PP_QUICK
+        if (sums) return pp_launch_one<bf16_t, 320, true, true>(a, stream);
+        if (taps) return pp_launch_one<bf16_t, 320, true, false>(a, stream);
+#endif
+        return pp_launch_one<bf16_t, 320, false, false>(a, stream);
     }
-    const int tiles = cdiv_i(a->M, 256) * cdiv_i(a->N, 256);
-    static int cxx_reads = -1;
-    if (cxx_reads < 0) {
-        const char* e = getenv("THEIA_PP_READS");
-        cxx_reads = (e != nullptr && strcmp(e, "cxx") == 0) ? 1 : 0;
-        if (cxx_reads) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    }
-    if (dtype == THEIA_FP8) {  // fp8 e4m3 operands (bytes), bf16 output
-        static bool attr8 = false;
-        if (!attr8) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<fp8_t, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<fp8_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            attr8 = true;
-        }
-        if (a->ln_sums != nullptr) hipLaunchKernelGGL((gemm_nt_pp_kernel<fp8_t, false, true>), dim3(tiles), dim3(512), lds, stream, *a);
-        else hipLaunchKernelGGL((gemm_nt_pp_kernel<fp8_t, false, false>), dim3(tiles), dim3(512), lds, stream, *a);
-    } else if (a->ln_sums != nullptr) {
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<bf16_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<float, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            attr2 = true;
-        }
-        if (dtype == THEIA_BF16) hipLaunchKernelGGL((gemm_nt_pp_kernel<bf16_t, false, true>), dim3(tiles), dim3(512), lds, stream, *a);
-        else hipLaunchKernelGGL((gemm_nt_pp_kernel<float, false, true>), dim3(tiles), dim3(512), lds, stream, *a);
-    } else if (dtype == THEIA_BF16 && cxx_reads) hipLaunchKernelGGL((gemm_nt_pp_kernel<bf16_t, true>), dim3(tiles), dim3(512), lds, stream, *a);
-    else if (dtype == THEIA_BF16) hipLaunchKernelGGL(gemm_nt_pp_kernel<bf16_t>, dim3(tiles), dim3(512), lds, stream, *a);
-    else hipLaunchKernelGGL(gemm_nt_pp_kernel<float>, dim3(tiles), dim3(512), lds, stream, *a);
-    THEIA_CHECK_LAUNCH("theia_gemm_nt(pp)");
-    return THEIA_OK;
+#ifndef PP_QUICK
+    if (sums) return pp_launch_one<bf16_t, 256, true, true>(a, stream);
+    if (taps) return pp_launch_one<bf16_t, 256, true, false>(a, stream);
+#endif
+    return pp_launch_one<bf16_t, 256, false, false>(a, stream);
+#endif
 }

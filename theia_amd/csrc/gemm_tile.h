@@ -82,6 +82,16 @@ __device__ __forceinline__ int gt_divmod(int m, int d, float rcp, int& rem) {
     return q;
 }
 
+// the same without the large-m branch (callers guarantee m < 2^24): no divergent control flow in the kernels' address set-up
+__device__ __forceinline__ int gt_divmod24(int m, int d, float rcp, int& rem) {
+    int q = (int)((float)m * rcp);
+    int r = m - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+    rem = r;
+    return q;
+}
+
 // fast exact-erf GELU pieces for the bf16 path: Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution);
 // the f32 (parity) path keeps libm erff.
 __device__ __forceinline__ float gt_erf_fast(float x) {

@@ -108,9 +108,10 @@ def _dt(t: torch.Tensor) -> int:
 
 
 # Tile request applied to every theia_gemm_nt launch that does not pass its own (0 = the library chooses).  Test / self-check
-# hook: the parity tests and bench.py's self-check run small batches through the 256x256 ping-pong kernel with 256256, and
-# cross-check the automatic choice at full size against the 2-stage kernel with 128128.  A 256256 request is applied only to
-# problems the ping-pong kernel takes (see pp_supported); N < 64-wide problems keep the library's 128x64 choice.
+# hook: the parity tests and bench.py's self-check run small batches through the persistent ping-pong kernel with 256256 (or
+# 320256: its 320-row tiles), and cross-check the automatic choice at full size against the 2-stage kernel with 128128.  A
+# ping-pong request is applied only to problems that kernel takes (theia_gemm_nt_plan decides); N < 64-wide problems keep the
+# library's 128x64 choice.
 GEMM_TILE_HINT = 0
 
 
@@ -126,7 +127,7 @@ GEMM_PROFILE: Optional[list] = None
 WGRAD_PROFILE: Optional[list] = None  # same for theia_gemm_wgrad launches
 
 
-KERNEL_NAMES = {128128: "128x128", 128064: "128x64", 256000: "256x256-2stage", 256256: "256x256", 256009: "256x256-conv"}
+KERNEL_NAMES = {128128: "128x128", 128064: "128x64", 256000: "256x256-2stage", 256256: "256x256", 320256: "320x256", 256009: "256x256-conv"}
 
 
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int, K: int, rmap: RowMap, ldw: int, ldo: int,
@@ -152,12 +153,12 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int
     if tile == 0 and GEMM_TILE_HINT != 0 and a.dtype != torch.float8_e4m3fn:
         if GEMM_TILE_HINT == 128128:
             tile = 128128 if N.lib().theia_gemm_nt_tile(M, Nn, _dt(a)) != 128064 else 0
-        elif N.lib().theia_gemm_nt_tile(M, Nn, _dt(a)) != 128064:  # 256256: every ping-pong kernel the problem admits
-            g.tile = 256009
-            if N.lib().theia_gemm_nt_plan(g, _dt(a)) == 256009:
-                tile = 256009
-            elif pp_supported(K, rmap.in_c, a.dtype):
-                tile = 256256
+        elif N.lib().theia_gemm_nt_tile(M, Nn, _dt(a)) != 128064:  # 256256 / 320256: every ping-pong kernel the problem admits
+            for req in (256009, GEMM_TILE_HINT):
+                g.tile = req
+                if N.lib().theia_gemm_nt_plan(g, _dt(a)) > 0:  # (a request the library cannot honour is an error code < 0)
+                    tile = req
+                    break
     g.tile = tile
     assert a.dtype == w.dtype and (a.dtype == out.dtype or a.dtype == torch.float8_e4m3fn)
     if plan_only:
