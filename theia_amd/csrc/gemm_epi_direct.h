@@ -115,122 +115,130 @@ template <typename T> struct gd_ctx_t {
     float ls0, lq0, ls1, lq1;
 };
 
-// One wave tile with a fixed activation.  PRE (bf16 only): the aux_in (MUL_D*) / residual rows are prefetched in chunks of CJ row
-// groups with inline-asm loads: chunk c+1 is requested before chunk c's stores are issued and waited for (vmcnt(0): loads and
-// stores share the counter and retire out of order with respect to each other) after them.
+template <int N> __device__ __forceinline__ void gd_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// 8 accumulator values of row group j, column half t -> bias / activation / residual applied (everything but the store)
+template <typename T, int FM, bool SCALE, bool BIAS_IN_ACC, int ACT>
+__device__ __forceinline__ void gd_apply(const gt_f32x4 (&acc)[4][FM], int j, int t, const gd_ctx_t<T>& cx, const float (&a8)[8], bool has_res,
+                                         const float (&r8)[8], float (&v)[8], float (&pre)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = acc[2 * t][j][e];
+        v[4 + e] = acc[2 * t + 1][j][e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if constexpr (SCALE) v[e] *= cx.alpha;
+        if constexpr (!BIAS_IN_ACC) v[e] += cx.bias8[t][e];
+        pre[e] = v[e];
+    }
+    if constexpr (ACT == THEIA_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gt_gelu<T>(v[e]);
+    } else if constexpr (ACT == THEIA_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if constexpr (ACT == THEIA_ACT_MUL_DGELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= gt_gelu_grad<T>(a8[e]);
+    } else if constexpr (ACT == THEIA_ACT_MUL_DRELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = a8[e] > 0.f ? v[e] : 0.f;
+    }
+    if (ACT == THEIA_ACT_NONE && has_res) {  // (the dispatch keeps residual + activation launches off this kernel)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r8[e];
+    }
+}
+
+// One wave tile with a fixed activation.
+// PRE (bf16, 128-row wave tiles): the aux_in (MUL_D*) / residual rows are read with inline-asm loads in three phases --
+//   A  all FM x 2 row pieces are requested (64 registers next to the 128 accumulators);
+//   B  row group by row group: a COUNTED wait (no store has been issued yet, so the counter holds loads only, and loads retire in
+//      order -- the next tile's operand fetches, requested earlier, retire first), the arithmetic, and the packed bf16 result is
+//      written back INTO the registers the row piece arrived in;
+//   C  all stores.
+// Loads and stores share the vmcnt counter and retire out of order with respect to each other, so a wait between stores is always a
+// wait for everything (the first version of this epilogue prefetched chunk c+1 around chunk c's stores and waited vmcnt(0) per chunk).
 template <typename T, int FM, bool SUMS, bool SCALE, bool BIAS_IN_ACC, int ACT, bool PRE>
 __device__ __forceinline__ void gd_epilogue_body(gt_f32x4 (&acc)[4][FM], const theia_gemm_args_t& p, const gd_rows_t& rw, int m_row0,
                                                  gd_ctx_t<T>& cx) {
     constexpr bool WANT_AUX = ACT == THEIA_ACT_MUL_DGELU || ACT == THEIA_ACT_MUL_DRELU;
-    constexpr int CJ = 2, NC = FM / CJ;
-    static_assert(FM % CJ == 0, "row groups are processed in pairs");
-    const T* __restrict__ PREP = WANT_AUX ? cx.AUXI : cx.RES;
     gd_rows_t::cursor_t cur = rw.first(p, m_row0);
-    gd_rows_t::cursor_t pc = cur;
-    gt_u32x4 rows[2][CJ][2];
     if constexpr (PRE) {
+        static_assert(sizeof(T) == 2 && !SUMS, "row prefetch: bf16 outputs, no statistics");
+        const T* __restrict__ PREP = WANT_AUX ? cx.AUXI : cx.RES;
+        gt_u32x4 rows[FM][2];
+        gd_rows_t::cursor_t pc = cur;
 #pragma unroll
-        for (int jj = 0; jj < CJ; ++jj) {
+        for (int j = 0; j < FM; ++j) {  // phase A; dead lanes read row 0 (valid memory)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const bool lv = (pc.m < p.M) && cx.nok[t];
-                gd_load16(rows[0][jj][t], PREP + (lv ? pc.off + cx.ncol[t] : cx.off_dead));
+                gd_load16(rows[j][t], PREP + (lv ? pc.off + cx.ncol[t] : cx.off_dead));
             }
             rw.next(pc);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        gd_static_for<0, FM>([&](auto J_C) {  // phase B
+            constexpr int j = decltype(J_C)::value;
+            gd_wait_vm<(FM - 1 - j) * 2>();
 #pragma unroll
-        for (int jj = 0; jj < CJ; ++jj)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(rows[0][jj][t]));
-    }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        if (PRE && c + 1 < NC) {  // rows of the next chunk; dead lanes read row 0 (valid memory)
-#pragma unroll
-            for (int jj = 0; jj < CJ; ++jj) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const bool lv = (pc.m < p.M) && cx.nok[t];
-                    gd_load16(rows[(c + 1) & 1][jj][t], PREP + (lv ? pc.off + cx.ncol[t] : cx.off_dead));
-                }
-                rw.next(pc);
+            for (int t = 0; t < 2; ++t) {
+                asm volatile("" : "+v"(rows[j][t]));
+                float a8[8], v[8], pre[8];
+                gd_unpack8(rows[j][t], a8);
+                gd_apply<T, FM, SCALE, BIAS_IN_ACC, ACT>(acc, j, t, cx, a8, !WANT_AUX, a8, v, pre);
+                rows[j][t] = (gt_u32x4){pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
             }
-        }
+        });
 #pragma unroll
-        for (int jj = 0; jj < CJ; ++jj) {
-            const int j = c * CJ + jj;
+        for (int j = 0; j < FM; ++j) {  // phase C
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const bool live = (cur.m < p.M) && cx.nok[t];
-                const int64_t o = live ? cur.off + cx.ncol[t] : cx.off_dead;
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[2 * t][j][e];
-                    v[4 + e] = acc[2 * t + 1][j][e];
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if constexpr (SCALE) v[e] *= cx.alpha;
-                    if constexpr (!BIAS_IN_ACC) v[e] += cx.bias8[t][e];
-                }
-                float a8[8];
-                if constexpr (WANT_AUX) {
-                    if constexpr (PRE) gd_unpack8(rows[c & 1][jj][t], a8);
-                    else load8(cx.AUXI + o, a8);
-                }
-                if constexpr (ACT == THEIA_ACT_GELU) {
-                    if (cx.AUXO != nullptr) store8(live ? cx.AUXO + o : cx.dump, v);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gt_gelu<T>(v[e]);
-                } else if constexpr (ACT == THEIA_ACT_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                } else if constexpr (ACT == THEIA_ACT_MUL_DGELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= gt_gelu_grad<T>(a8[e]);
-                } else if constexpr (ACT == THEIA_ACT_MUL_DRELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = a8[e] > 0.f ? v[e] : 0.f;
-                }
-                if (ACT == THEIA_ACT_NONE && cx.RES != nullptr) {  // (the dispatch keeps residual + activation launches off this kernel)
-                    float r8[8];
-                    if constexpr (PRE) gd_unpack8(rows[c & 1][jj][t], r8);
-                    else load8(cx.RES + o, r8);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += r8[e];
-                }
-                store8(live ? cx.O + o : cx.dump, v);
-                if constexpr (SUMS) {
-                    float s = 0.f, sq = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float r = sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(v[e])) : v[e];  // the value as stored
-                        s += r;
-                        sq += r * r;
-                    }
-                    s = live ? s : 0.f;
-                    sq = live ? sq : 0.f;
-                    const bool first = cur.m < cx.m_split;
-                    cx.ls0 += first ? s : 0.f;
-                    cx.lq0 += first ? sq : 0.f;
-                    cx.ls1 += first ? 0.f : s;
-                    cx.lq1 += first ? 0.f : sq;
-                    // pin the running sums here: left alone, the optimiser sinks the whole reduction behind the last block and keeps
-                    // every block's 8 stored values alive for it (128 registers: scratch spills)
-                    asm volatile("" : "+v"(cx.ls0), "+v"(cx.lq0), "+v"(cx.ls1), "+v"(cx.lq1));
-                }
+                T* dst = live ? cx.O + cur.off + cx.ncol[t] : cx.dump;
+                *reinterpret_cast<gt_u32x4*>(dst) = rows[j][t];
             }
             rw.next(cur);
         }
-        if (PRE && c + 1 < NC) {  // the next chunk's rows were requested before this chunk's stores: one wait for both
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
 #pragma unroll
-            for (int jj = 0; jj < CJ; ++jj)
+    for (int j = 0; j < FM; ++j) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(rows[(c + 1) & 1][jj][t]));
+        for (int t = 0; t < 2; ++t) {
+            const bool live = (cur.m < p.M) && cx.nok[t];
+            const int64_t o = live ? cur.off + cx.ncol[t] : cx.off_dead;
+            float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v[8], pre[8];
+            if constexpr (WANT_AUX) load8(cx.AUXI + o, a8);
+            const bool has_res = ACT == THEIA_ACT_NONE && cx.RES != nullptr;
+            if (has_res) load8(cx.RES + o, r8);
+            gd_apply<T, FM, SCALE, BIAS_IN_ACC, ACT>(acc, j, t, cx, a8, has_res, r8, v, pre);
+            if constexpr (ACT == THEIA_ACT_GELU) {
+                if (cx.AUXO != nullptr) store8(live ? cx.AUXO + o : cx.dump, pre);
+            }
+            store8(live ? cx.O + o : cx.dump, v);
+            if constexpr (SUMS) {
+                float s = 0.f, sq = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float r = sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(v[e])) : v[e];  // the value as stored
+                    s += r;
+                    sq += r * r;
+                }
+                s = live ? s : 0.f;
+                sq = live ? sq : 0.f;
+                const bool first = cur.m < cx.m_split;
+                cx.ls0 += first ? s : 0.f;
+                cx.lq0 += first ? sq : 0.f;
+                cx.ls1 += first ? 0.f : s;
+                cx.lq1 += first ? 0.f : sq;
+                // pin the running sums here: left alone, the optimiser sinks the whole reduction behind the last block and keeps
+                // every block's 8 stored values alive for it (128 registers: scratch spills)
+                asm volatile("" : "+v"(cx.ls0), "+v"(cx.lq0), "+v"(cx.ls1), "+v"(cx.lq1));
+            }
         }
+        rw.next(cur);
     }
 }
 
@@ -273,7 +281,7 @@ __device__ __forceinline__ void gd_epilogue(gt_f32x4 (&acc)[4][FM], const theia_
     cx.ls0 = cx.lq0 = cx.ls1 = cx.lq1 = 0.f;
     // the row prefetch costs 32 registers: the 160-row wave tile and the statistics epilogues (whose launches never carry an
     // aux_in / residual row: the dispatch sends that combination elsewhere) read such rows with plain loads instead
-    constexpr bool CAN_PRE = sizeof(T) == 2 && FM <= 8 && !SUMS;
+    constexpr bool CAN_PRE = sizeof(T) == 2 && FM <= 8 && !SUMS && BIAS_IN_ACC;  // (fp8 operands: 16 bias registers more, no room)
     const int m_row0 = m_wave0 + frow;
     if constexpr (SUMS) {  // the statistics launches are the convolutions in front of a LayerNorm[C,H,W]: no activation or ReLU
         if (p.act == THEIA_ACT_RELU) gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_RELU, false>(acc, p, rw, m_row0, cx);

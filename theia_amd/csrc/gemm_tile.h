@@ -92,23 +92,36 @@ __device__ __forceinline__ int gt_divmod24(int m, int d, float rcp, int& rem) {
     return q;
 }
 
-// fast exact-erf GELU pieces for the bf16 path: Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution);
-// the f32 (parity) path keeps libm erff.
-__device__ __forceinline__ float gt_erf_fast(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float r = 1.0f - poly * __expf(-ax * ax);
-    return copysignf(r, x);
+// GELU pieces of the bf16 path.  The f32 (parity) path keeps libm erff.
+// Phi(x) = 0.5 * (1 + erf(x / sqrt 2)) as an odd polynomial: Phi(x) = 0.5 + xc * P((xc / 4.5)^2), xc = clamp(x, +-4.5), P of degree 9
+// (weighted least-squares fit iterated towards minimax; evaluated in f32 Horner form: |error| <= 1.25e-5 over the whole real line,
+// the clamp's tail 1 - Phi(4.5) = 3.4e-6 included; bf16 resolves 3.9e-3).  13 plain VALU operations, no transcendental: the
+// Abramowitz-Stegun 7.1.26 form used before (rcp + exp + 14 plain, |error| 1.5e-7) made the GELU epilogue of a 256x256 tile ~15k
+// cycles and the GELU-gradient epilogue ~26k -- VALU-bound, a third / half of a K = 768 tile (tools/pp_bench.hip -DPP_TRACE).
+__device__ __forceinline__ float gt_phi_poly(float x) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -4.5f, 4.5f);
+    const float xs = xc * (1.0f / 4.5f);
+    const float s = xs * xs;
+    float p = -1.050371170e+00f;
+    p = fmaf(p, s, 6.019040585e+00f);
+    p = fmaf(p, s, -1.537067318e+01f);
+    p = fmaf(p, s, 2.330106735e+01f);
+    p = fmaf(p, s, -2.366455650e+01f);
+    p = fmaf(p, s, 1.729463768e+01f);
+    p = fmaf(p, s, -9.533602715e+00f);
+    p = fmaf(p, s, 4.061982155e+00f);
+    p = fmaf(p, s, -1.345344782e+00f);
+    p = fmaf(p, s, 3.989298940e-01f);
+    return fmaf(xc, p, 0.5f);
 }
 template <typename T> __device__ __forceinline__ float gt_gelu(float x) {
-    if constexpr (sizeof(T) == 2) return 0.5f * x * (1.0f + gt_erf_fast(x * 0.70710678118654752440f));
+    if constexpr (sizeof(T) == 2) return x * gt_phi_poly(x);
     else return gelu_erf(x);
 }
 template <typename T> __device__ __forceinline__ float gt_gelu_grad(float x) {
-    if constexpr (sizeof(T) == 2) {
-        const float cdf = 0.5f * (1.0f + gt_erf_fast(x * 0.70710678118654752440f));
-        return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+    if constexpr (sizeof(T) == 2) {  // Phi(x) + x * phi(x), phi = exp(-x^2 / 2) / sqrt(2 pi) through one v_exp_f32
+        const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
+        return fmaf(x * e, 0.39894228040143267794f, gt_phi_poly(x));
     } else {
         return gelu_erf_grad(x);
     }

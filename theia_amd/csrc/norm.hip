@@ -243,50 +243,73 @@ extern "C" size_t theia_layernorm_chw_workspace_bytes(int b, int64_t E) {
 }
 
 // partial (sum a, sum b) per (sample, chunk).  MODE 0: a = x, b = x*x.  MODE 1: a = dy*g, b = dy*g*xhat.
+// A block owns one chunk of the element axis and walks over a GROUP of samples (blockIdx.y = group): the f32 affine row of the
+// chunk (MODE 1) is loaded once per block and kept in registers -- one block per (chunk, sample) re-read 4 B of gamma for every
+// 4 B of x and dy (PMC, round 2: 3.3x the algorithmic HBM reads on the LayerNorm[C,H,W] kernels).
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void chw_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const float* __restrict__ gamma, const float* __restrict__ stats,
-                                                          float* __restrict__ part, int64_t E, int nchunks) {
+                                                          float* __restrict__ part, int64_t E, int nchunks, int b, int ngroups) {
     __shared__ float red[8];
-    const int sample = blockIdx.y, chunk = blockIdx.x;
-    const int64_t base = (int64_t)sample * E;
-    float mu = 0.f, rs = 0.f;
+    constexpr int IT = CHW_CHUNK / (256 * 8);
+    const int chunk = blockIdx.x, grp = blockIdx.y;
+    const int per = (b + ngroups - 1) / ngroups;
+    const int s0 = grp * per, s1 = min(b, s0 + per);
+    float g8[MODE == 1 ? IT : 1][8];
     if (MODE == 1) {
-        mu = stats[2 * sample];
-        rs = stats[2 * sample + 1];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int64_t e = (int64_t)chunk * CHW_CHUNK + (it * 256 + threadIdx.x) * 8;
+            if (e < E) load8(gamma + e, g8[it]);
+        }
     }
-    float sa = 0.f, sb = 0.f;
+    for (int sample = s0; sample < s1; ++sample) {
+        const int64_t base = (int64_t)sample * E;
+        float mu = 0.f, rs = 0.f;
+        if (MODE == 1) {
+            mu = stats[2 * sample];
+            rs = stats[2 * sample + 1];
+        }
+        float sa = 0.f, sb = 0.f;
 #pragma unroll
-    for (int it = 0; it < CHW_CHUNK / (256 * 8); ++it) {
-        const int64_t e = (int64_t)chunk * CHW_CHUNK + (it * 256 + threadIdx.x) * 8;
-        if (e < E) {
-            float xv[8];
-            load8(x + base + e, xv);
-            if (MODE == 0) {
+        for (int it = 0; it < IT; ++it) {
+            const int64_t e = (int64_t)chunk * CHW_CHUNK + (it * 256 + threadIdx.x) * 8;
+            if (e < E) {
+                float xv[8];
+                load8(x + base + e, xv);
+                if (MODE == 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    sa += xv[j];
-                    sb += xv[j] * xv[j];
-                }
-            } else {
-                float dv[8], g8[8];
-                load8(dy + base + e, dv);
-                load8(gamma + e, g8);
+                    for (int j = 0; j < 8; ++j) {
+                        sa += xv[j];
+                        sb += xv[j] * xv[j];
+                    }
+                } else {
+                    float dv[8];
+                    load8(dy + base + e, dv);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float gy = dv[j] * g8[j];
-                    sa += gy;
-                    sb += gy * (xv[j] - mu) * rs;
+                    for (int j = 0; j < 8; ++j) {
+                        const float gy = dv[j] * g8[MODE == 1 ? it : 0][j];
+                        sa += gy;
+                        sb += gy * (xv[j] - mu) * rs;
+                    }
                 }
             }
         }
+        sa = block_sum<256>(sa, red);
+        sb = block_sum<256>(sb, red + 4);
+        if (threadIdx.x == 0) {
+            part[((int64_t)sample * nchunks + chunk) * 2] = sa;
+            part[((int64_t)sample * nchunks + chunk) * 2 + 1] = sb;
+        }
     }
-    sa = block_sum<256>(sa, red);
-    sb = block_sum<256>(sb, red + 4);
-    if (threadIdx.x == 0) {
-        part[((int64_t)sample * nchunks + chunk) * 2] = sa;
-        part[((int64_t)sample * nchunks + chunk) * 2 + 1] = sb;
-    }
+}
+
+// sample groups of the statistics / apply passes: enough blocks to fill the chip (>= ~2048 blocks), each walking over b / groups samples
+static int chw_sample_groups(int b, int64_t col_blocks) {
+    int64_t g = (2048 + col_blocks - 1) / col_blocks;
+    if (g > b) g = b;
+    if (g < 1) g = 1;
+    return (int)g;
 }
 
 // MODE 0: stats[s] = (mean, rstd).  MODE 1: stats_out[s] = (mean(dy*g), mean(dy*g*xhat)).
@@ -317,34 +340,44 @@ __global__ void chw_finalize_kernel(const float* __restrict__ part, float* __res
 template <typename T, bool SUMS = false>
 __global__ __launch_bounds__(256) void chw_apply_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ stats,
-                                                        T* __restrict__ y, int64_t E, float* __restrict__ stats_out = nullptr,
+                                                        T* __restrict__ y, int64_t E, int b, int ngroups, float* __restrict__ stats_out = nullptr,
                                                         float eps = 0.f) {
-    const int sample = blockIdx.y;
-    float mu, rs;
-    if constexpr (SUMS) {  // 2^-24 fixed-point 64-bit sums (gt_epilogue)
-        const long long* fx = reinterpret_cast<const long long*>(stats);
-        const double m = (double)fx[2 * sample] * (1.0 / 16777216.0) / (double)E;
-        double var = (double)fx[2 * sample + 1] * (1.0 / 16777216.0) / (double)E - m * m;
-        if (var < 0.0) var = 0.0;
-        mu = (float)m;
-        rs = (float)(1.0 / sqrt(var + (double)eps));
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            stats_out[2 * sample] = mu;
-            stats_out[2 * sample + 1] = rs;
-        }
-    } else {
-        mu = stats[2 * sample];
-        rs = stats[2 * sample + 1];
-    }
+    // a block owns 2048 elements of the affine row (f32 gamma / beta: 8 B per element, in registers) and walks over its group of
+    // samples -- the round-2 kernel (one block per sample) re-read those 8 B for every 2 B of x
+    const int grp = blockIdx.y;
+    const int per = (b + ngroups - 1) / ngroups;
+    const int s0 = grp * per, s1 = min(b, s0 + per);
     const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    if (e >= E) return;
-    float xv[8], g8[8], b8[8], o[8];
-    load8(x + (int64_t)sample * E + e, xv);
-    load8(gamma + e, g8);
-    load8(beta + e, b8);
+    const bool live = e < E;
+    float g8[8], b8[8];
+    if (live) {
+        load8(gamma + e, g8);
+        load8(beta + e, b8);
+    }
+    for (int sample = s0; sample < s1; ++sample) {
+        float mu, rs;
+        if constexpr (SUMS) {  // 2^-24 fixed-point 64-bit sums (GEMM epilogues)
+            const long long* fx = reinterpret_cast<const long long*>(stats);
+            const double m = (double)fx[2 * sample] * (1.0 / 16777216.0) / (double)E;
+            double var = (double)fx[2 * sample + 1] * (1.0 / 16777216.0) / (double)E - m * m;
+            if (var < 0.0) var = 0.0;
+            mu = (float)m;
+            rs = (float)(1.0 / sqrt(var + (double)eps));
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                stats_out[2 * sample] = mu;
+                stats_out[2 * sample + 1] = rs;
+            }
+        } else {
+            mu = stats[2 * sample];
+            rs = stats[2 * sample + 1];
+        }
+        if (!live) continue;
+        float xv[8], o[8];
+        load8(x + (int64_t)sample * E + e, xv);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (xv[j] - mu) * rs * g8[j] + b8[j];
-    store8(y + (int64_t)sample * E + e, o);
+        for (int j = 0; j < 8; ++j) o[j] = (xv[j] - mu) * rs * g8[j] + b8[j];
+        store8(y + (int64_t)sample * E + e, o);
+    }
 }
 
 extern "C" int theia_layernorm_chw_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
@@ -355,17 +388,19 @@ extern "C" int theia_layernorm_chw_fwd(const void* x, const float* gamma, const 
     const int nch = chw_chunks(E);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == THEIA_BF16)
-        hipLaunchKernelGGL((chw_partial_kernel<bf16_t, 0>), dim3(nch, b), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, E, nch);
+        hipLaunchKernelGGL((chw_partial_kernel<bf16_t, 0>), dim3(nch, b), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, E, nch, b, b);
     else
-        hipLaunchKernelGGL((chw_partial_kernel<float, 0>), dim3(nch, b), dim3(256), 0, s, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, E, nch);
+        hipLaunchKernelGGL((chw_partial_kernel<float, 0>), dim3(nch, b), dim3(256), 0, s, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace, E, nch, b, b);
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_fwd(partial)");
     hipLaunchKernelGGL(chw_finalize_kernel<0>, dim3((b + 63) / 64), dim3(64), 0, s, workspace, stats, b, nch, E, eps);
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_fwd(finalize)");
-    const dim3 grid((unsigned)((E / 8 + 255) / 256), b);
+    const int64_t colb = (E / 8 + 255) / 256;
+    const int ng = chw_sample_groups(b, colb);
+    const dim3 grid((unsigned)colb, ng);
     if (dtype == THEIA_BF16)
-        hipLaunchKernelGGL((chw_apply_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (const float*)stats, (bf16_t*)y, E, (float*)nullptr, 0.f);
+        hipLaunchKernelGGL((chw_apply_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (const float*)stats, (bf16_t*)y, E, b, ng, (float*)nullptr, 0.f);
     else
-        hipLaunchKernelGGL((chw_apply_kernel<float, false>), grid, dim3(256), 0, s, (const float*)x, gamma, beta, (const float*)stats, (float*)y, E, (float*)nullptr, 0.f);
+        hipLaunchKernelGGL((chw_apply_kernel<float, false>), grid, dim3(256), 0, s, (const float*)x, gamma, beta, (const float*)stats, (float*)y, E, b, ng, (float*)nullptr, 0.f);
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_fwd(apply)");
     return THEIA_OK;
 }
@@ -376,11 +411,13 @@ extern "C" int theia_layernorm_chw_fwd_sums(const void* x, const float* gamma, c
     THEIA_CHECK_ARG(b > 0 && E > 0 && E % 8 == 0, "theia_layernorm_chw_fwd_sums: E=%lld must be a positive multiple of 8", (long long)E);
     THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16, "theia_layernorm_chw_fwd_sums: bad dtype");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)((E / 8 + 255) / 256), b);
+    const int64_t colb = (E / 8 + 255) / 256;
+    const int ng = chw_sample_groups(b, colb);
+    const dim3 grid((unsigned)colb, ng);
     if (dtype == THEIA_BF16)
-        hipLaunchKernelGGL((chw_apply_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, sums, (bf16_t*)y, E, stats, eps);
+        hipLaunchKernelGGL((chw_apply_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, sums, (bf16_t*)y, E, b, ng, stats, eps);
     else
-        hipLaunchKernelGGL((chw_apply_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, gamma, beta, sums, (float*)y, E, stats, eps);
+        hipLaunchKernelGGL((chw_apply_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, gamma, beta, sums, (float*)y, E, b, ng, stats, eps);
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_fwd_sums");
     return THEIA_OK;
 }
@@ -435,10 +472,11 @@ extern "C" int theia_layernorm_chw_bwd(const void* dy, const void* x, const floa
     float* dstat = part_stats + (((size_t)b * nch * 2 + 63) / 64) * 64;
     float* parts = dstat + (((size_t)b * 2 + 63) / 64) * 64;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int ngp = chw_sample_groups(b, nch);
     if (dtype == THEIA_BF16)
-        hipLaunchKernelGGL((chw_partial_kernel<bf16_t, 1>), dim3(nch, b), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, gamma, stats, part_stats, E, nch);
+        hipLaunchKernelGGL((chw_partial_kernel<bf16_t, 1>), dim3(nch, ngp), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, gamma, stats, part_stats, E, nch, b, ngp);
     else
-        hipLaunchKernelGGL((chw_partial_kernel<float, 1>), dim3(nch, b), dim3(256), 0, s, (const float*)x, (const float*)dy, gamma, stats, part_stats, E, nch);
+        hipLaunchKernelGGL((chw_partial_kernel<float, 1>), dim3(nch, ngp), dim3(256), 0, s, (const float*)x, (const float*)dy, gamma, stats, part_stats, E, nch, b, ngp);
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_bwd(partial)");
     hipLaunchKernelGGL(chw_finalize_kernel<1>, dim3((b + 63) / 64), dim3(64), 0, s, part_stats, dstat, b, nch, E, 0.f);
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_bwd(finalize)");
