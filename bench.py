@@ -55,9 +55,15 @@ TEACHERS = [
     "facebook/sam-vit-huge",
     "LiheYoung/depth-anything-large-hf",
 ]
+TEACHER_SETS = {  # configs/training/target_models/{dinov2,cdiv,cddsv}.yaml of the reference (dict order = head order)
+    "dinov2": ["facebook/dinov2-large"],
+    "cdiv": ["google/vit-huge-patch14-224-in21k", "facebook/dinov2-large", "openai/clip-vit-large-patch14"],
+    "cddsv": list(TEACHERS),
+}
 FLOPS_PER_IMAGE_FWD_BWD = 272.169e9   # BASELINE.md sec. 3 (2xMAC, fwd+bwd, base + cddsv)
-FLOPS_PER_IMAGE_BY_BACKBONE = {"facebook/deit-base-patch16-224": 272.169e9, "facebook/deit-small-patch16-224": 71.571e9,
-                               "facebook/deit-tiny-patch16-224": None}  # C3, C4 (5 teachers)
+# C1 (tiny + dinov2), C2 (tiny + cdiv), C3 (base + cddsv), C4 (small + cddsv); other combinations: not tabulated
+FLOPS_PER_IMAGE = {("facebook/deit-base-patch16-224", "cddsv"): 272.169e9, ("facebook/deit-small-patch16-224", "cddsv"): 71.571e9,
+                   ("facebook/deit-tiny-patch16-224", "cdiv"): 12.673e9, ("facebook/deit-tiny-patch16-224", "dinov2"): 9.175e9}
 FLOPS_PER_IMAGE_STUDENT = 105.147e9   # DeiT-base backbone only, fwd+bwd
 FLOPS_PER_IMAGE_FWD = 35.126e9        # DeiT-base forward
 MFMA_BF16_PEAK = 2.5e15               # dense, /opt/skills/guides/MI355X_MICROARCH.md
@@ -71,6 +77,9 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--backbone", default=BACKBONE)
+    ap.add_argument("--teachers", default="cddsv", choices=sorted(TEACHER_SETS),
+                    help="teacher set (reference configs/training/target_models/*.yaml): cddsv = 5 teachers (BASELINE configs[2..3]), "
+                         "cdiv = ViT-H + DINOv2 + CLIP (configs[1]), dinov2 = 1 teacher (configs[0])")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"],
                     help="fp8: BASELINE configs[3] mode (with --backbone facebook/deit-small-patch16-224 --batch 256)")
     ap.add_argument("--mode", default="train", choices=["train", "forward_feature"])
@@ -318,6 +327,10 @@ def main(argv=None):
     args = parse(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         self_spawn(args, argv)
+    TEACHERS[:] = TEACHER_SETS[args.teachers]
+    global METRIC
+    if (args.backbone, args.teachers) != (BACKBONE, "cddsv"):  # the BASELINE metric string names DeiT-base + 5 teachers
+        METRIC = (f"images/sec train-step (fwd+bwd+allreduce) {args.backbone.split('/')[-1]} {len(TEACHERS)}-teacher ({args.teachers})")
     import torch
     import torch.distributed as dist
     if os.environ.get("THEIA_BENCH_DEBUG"):  # dump every thread's stack if the run is still going after N seconds
@@ -341,6 +354,8 @@ def main(argv=None):
         if one_device:
             dist.init_process_group("gloo")
         else:
+            from theia_amd.parallel import configure_rccl_env
+            configure_rccl_env()  # THEIA_RCCL_MAX_NCHANNELS -> NCCL_MAX_NCHANNELS
             dist.init_process_group("nccl", device_id=dev)
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)  # the first collective: counts the ranks RCCL actually connected
@@ -566,7 +581,7 @@ def main(argv=None):
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "fp8": "fp8 e4m3 operands (fwd + dgrad GEMMs), f32 accumulate, bf16 out; bf16 wgrad"}.get(args.precision, "f32"),
             "data": "synthetic",
-            "config": {"workload": f"{args.backbone.split('/')[-1]} student + 5 teachers (cddsv), per-GPU batch {b}, "
+            "config": {"workload": f"{args.backbone.split('/')[-1]} student + {len(TEACHERS)} teacher{'s' if len(TEACHERS) > 1 else ''} ({args.teachers}), per-GPU batch {b}, "
                                    f"loss 0.9*cos+0.1*smoothL1, step = fwd+loss+bwd+grad all-reduce" +
                                    ("" if args.no_optimizer else "+fused AdamW"),
                        "global_batch": b * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
@@ -574,8 +589,8 @@ def main(argv=None):
             "host_enqueue_ms_per_step": round(host_dt * 1e3, 3),
             "rccl_ranks": rccl_ranks,
             "selfcheck": checks if checks else "skipped (--no-selfcheck): unchecked run",
-            "model_flops_utilization": round(value / world * FLOPS_PER_IMAGE_BY_BACKBONE[args.backbone] / MFMA_BF16_PEAK, 4)
-            if FLOPS_PER_IMAGE_BY_BACKBONE.get(args.backbone) else None,
+            "model_flops_utilization": round(value / world * FLOPS_PER_IMAGE[(args.backbone, args.teachers)] / MFMA_BF16_PEAK, 4)
+            if FLOPS_PER_IMAGE.get((args.backbone, args.teachers)) else None,
         }
         if args.backbone != BACKBONE:
             out["metric"] = f"images/sec train-step (fwd+bwd+allreduce) {args.backbone.split('/')[-1]} 5-teacher"

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define THEIA_ABI_VERSION 3
+#define THEIA_ABI_VERSION 4
 
 enum { THEIA_OK = 0, THEIA_ERR_INVALID = -1, THEIA_ERR_LAUNCH = -2, THEIA_ERR_UNSUPPORTED = -3 };
 enum { THEIA_F32 = 0, THEIA_BF16 = 1,
@@ -102,13 +102,17 @@ typedef struct theia_gemm_args {
     int32_t ldo;
     int32_t act;
     theia_rowmap_t map;
-    /* tile request: 0 = let the launcher choose (theia_gemm_nt_tile); 128128 / 128064 = the 2-stage kernel with that tile;
-     * 256256 = the 256x256 ping-pong kernel; 256009 = the 256x256 ping-pong kernel for 3x3 stride-1 convolutions whose
-     * 256-row tile is one 16x16 output image (the input slice is staged once, the 9 taps read shifted rows of it).
-     * A request the problem does not meet (K % 32 == 0 for bf16 / % 16 for f32, one tap's row <= 16 KiB; 256009: 9 taps on a
-     * full 3x3 grid, stride 1, rows_h = rows_w = 16, M % 256 == 0) is THEIA_ERR_UNSUPPORTED, never a fall-back, so a
-     * successful forced call proves which kernel ran (the parity tests force every kernel on small shapes; bench.py
-     * cross-checks the automatic choice against a forced one). */
+    /* tile request: 0 = let the launcher choose (theia_gemm_nt_tile / theia_gemm_nt_plan); 128128 / 128064 = the 2-stage kernel with
+     * that tile; 256256 / 320256 = the persistent ping-pong kernel (gemm_pp.hip) with 256- / 320-row tiles (320: bf16 only; the
+     * launcher picks it on its own when that saves whole rounds of the grid, e.g. 25216 x 768 outputs: 237 tiles = one round instead
+     * of 297 = two); 256009 = the 256x256 ping-pong kernel for 3x3 stride-1 convolutions whose 256-row tile is one 16x16 output
+     * image (the input slice is staged once, the 9 taps read shifted rows of it).
+     * A request the problem does not meet is THEIA_ERR_UNSUPPORTED, never a fall-back, so a successful forced call proves which
+     * kernel ran (the parity tests force every kernel on small shapes; bench.py cross-checks the automatic choice against a
+     * forced one).  The ping-pong kernel takes: K and in_c multiples of 32 (bf16) / 16 (f32) / 64 (fp8), one tap's row <= 16 KiB,
+     * M < 2^24, rows whose 16-row step wraps at most once per image row and per image (or plain matrices), no rowtab, a residual
+     * only with act NONE, ln_sums only with act NONE / RELU and without residual / aux_in (such launches run the 2-stage kernels
+     * when the choice is the launcher's).  256009: 9 taps on a full 3x3 grid, stride 1, rows_h = rows_w = 16, M % 256 == 0. */
     int32_t tile;
     int32_t reserved;
     /* optional: int64 [images][2] (declared float* for ABI stability: 16 bytes per image), accumulated atomically with the
@@ -335,6 +339,23 @@ int theia_scatter_tokens(const void* src, void* dst, int b, int nsrc, int ndst, 
  * p -= lr*(m_hat/(sqrt(v_hat)+eps) + wd*p) with decoupled weight decay; segments give per-range wd. */
 int theia_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, float bias_c1, float bias_c2, float grad_scale, void* stream);
+/* the same with the gradient scale read from device memory (*grad_scale_dev): the clip coefficient of theia_grad_clip_coef */
+int theia_adamw_step_scaled(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, float bias_c1, float bias_c2, const float* grad_scale_dev, void* stream);
+
+/* dst[i] = float(src_bf16[i]) * scale: widens a bf16 gradient-exchange buffer back into the fp32 gradient bucket after the RCCL
+ * all-reduce (the optional bf16 exchange of theia_amd/parallel.py; replaces nothing in the reference, whose DDP exchanges fp32:
+ * train_rvfm.py:258).  Both buffers 16-byte aligned. */
+int theia_upcast_scale_bf16(const void* src_bf16, float* dst, int64_t n, float scale, void* stream);
+
+/* Global-norm gradient clipping over flat f32 gradient ranges (nn.utils.clip_grad_norm_ at train_rvfm.py:126-130) without a host
+ * round trip.  theia_grad_sumsq: partials[0 .. theia_grad_sumsq_blocks()) = partial sums of squares of g[0..n) (g 16-byte aligned;
+ * fixed block order: bit-reproducible).  theia_grad_clip_coef: out2[0] = sqrt(sum of the nparts partials) = total norm,
+ * out2[1] = min(1, max_norm / (total + 1e-6)) -- the factor torch multiplies every gradient with; here it goes to
+ * theia_adamw_step_scaled, the gradient buffers themselves are left unscaled. */
+int theia_grad_sumsq_blocks(void);
+int theia_grad_sumsq(const float* g, int64_t n, float* partials, void* stream);
+int theia_grad_clip_coef(const float* partials, int nparts, float max_norm, float* out2, void* stream);
 
 /* hardware probe used by tests: transposed LDS read semantics of ds_read_b64_tr_b16 (out: 64 lanes x 4 u16) */
 int theia_probe_tr16(const uint16_t* lds_image_1024, const int32_t* lane_byte_addr_64, uint16_t* out_256,

@@ -86,31 +86,62 @@ def test_dp2_gloo_bucket_reduction_matches_single_process(golden_dir):
         assert abs(gn[k] - ref) < 1e-3 * ref, (k, gn[k], ref)
 
 
-def _worker_async_order(rank, world, port, ret):
+def _worker_async_order(rank, world, port, ret, exchange="allreduce", comm_dtype="fp32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
     sys.path.insert(0, ROOT)
-    from theia_amd.parallel import GradBucketReducer
-    red = GradBucketReducer()
-    flats = [torch.full((1000 + 8 * i,), float(rank + 1) * (i + 1)) for i in range(5)]
+    from theia_amd.parallel import GradBucketReducer, broadcast_parameters
+    red = GradBucketReducer(exchange=exchange, comm_dtype=comm_dtype)
+    # bucket sizes: multiples of 8 like the engine's (divisible by the world size), one that is not (falls back to one all-reduce)
+    flats = [torch.full((1000 + 8 * i,), float(rank + 1) * (i + 1)) for i in range(5)] + [torch.full((1001,), float(rank + 1))]
+    flats[2][7] = 0.1 * (rank + 1) + 3.0  # a value bf16 cannot hold exactly: the bf16 exchange rounds, the fp32 one must not
     for f in flats:
         red.bucket_ready(f)
     red.finish()
-    ok = all(torch.allclose(f, torch.full_like(f, 1.5 * (i + 1))) for i, f in enumerate(flats))
+    want = [torch.full_like(f, 1.5 * (i + 1)) for i, f in enumerate(flats[:5])] + [torch.full((1001,), 1.5)]
+    want[2][7] = 0.15 + 3.0
+    tol = dict(rtol=0, atol=0) if comm_dtype == "fp32" else dict(rtol=8e-3, atol=0)
+    ok = all(torch.allclose(f, w, **(tol if comm_dtype == "bf16" else {})) for f, w in zip(flats, want))
+    if comm_dtype == "fp32":
+        ok = ok and abs(float(flats[2][7]) - 3.15) < 1e-6
+    else:
+        ok = ok and float(flats[2][7]) != 3.15 and abs(float(flats[2][7]) - 3.15) < 0.02  # went through bf16
     red.finish()  # idempotent
+    # coalesced parameter broadcast: mixed shapes / dtypes, more bytes than one flat buffer
+    torch.manual_seed(7 + rank)
+    ps = [torch.randn(33, 5), torch.randn(7), torch.randn(4, 4, 4).double(), torch.randn(1000), torch.randn(3)]
+    broadcast_parameters(ps, 0, bucket_bytes=2048)
+    torch.manual_seed(7)
+    ref = [torch.randn(33, 5), torch.randn(7), torch.randn(4, 4, 4).double(), torch.randn(1000), torch.randn(3)]
+    ok = ok and all(torch.equal(a, b) for a, b in zip(ps, ref))
     if rank == 0:
         ret["ok"] = ok
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_reducer_averages_several_buckets_async():
+@pytest.mark.parametrize("exchange,comm_dtype", [("allreduce", "fp32"), ("rs_ag", "fp32"), ("allreduce", "bf16"), ("rs_ag", "bf16")])
+def test_reducer_averages_several_buckets_async(exchange, comm_dtype):
+    """every exchange form of GradBucketReducer (one all-reduce per bucket / reduce-scatter + all-gather on the flat buffer, fp32 / bf16
+    on the wire) + the coalesced parameter broadcast, world size 2"""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker_async_order, args=(2, _free_port(), ret), nprocs=2, join=True)
+    mp.spawn(_worker_async_order, args=(2, _free_port(), ret, exchange, comm_dtype), nprocs=2, join=True)
     assert ret["ok"]
+
+
+def test_rccl_channel_cap_knob(monkeypatch):
+    from theia_amd.parallel import configure_rccl_env
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    monkeypatch.delenv("THEIA_RCCL_MAX_NCHANNELS", raising=False)
+    configure_rccl_env()
+    assert "NCCL_MAX_NCHANNELS" not in os.environ
+    monkeypatch.setenv("THEIA_RCCL_MAX_NCHANNELS", "8")
+    configure_rccl_env()
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "8"
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
 
 
 def test_single_process_reducer_is_a_noop():

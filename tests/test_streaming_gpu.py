@@ -66,3 +66,50 @@ def test_streamed_matches_reference_golden(golden_dir):
     feat = m.forward_feature_streamed(O.synth_images(8, 0).to("cuda:0"), chunk=3)
     f = feat.float().cpu().numpy().reshape(-1)
     assert np.abs(f[g["feat_idx"]] - g["feat_val"]).max() / np.abs(g["feat_val"]).max() < 1e-4
+
+
+def test_streamed_base_bf16_matches_the_oracle():
+    """BASELINE configs[4]'s own model and precision: DeiT-base, bf16, streamed through the captured graph (ragged last chunk) ==
+    the eager forward_feature bit for bit, and within bf16 accuracy of the CPU oracle's fp32 features (max-norm 2e-2, cosine > 0.9995)."""
+    bb = "facebook/deit-base-patch16-224"
+    m = _model(bb, "bf16")
+    B, chunk = 40, 16
+    imgs = O.synth_images(B, 3)
+    with torch.no_grad():  # eager in the streamer's own chunking: the GEMM tile choice (hence the f32 summation order) follows the batch size
+        eager = torch.cat([m.forward_feature(imgs[i:i + chunk]) for i in range(0, 32, chunk)] + [m.forward_feature(torch.cat([imgs[32:], imgs[:8]]))[:8]])
+    got = m.forward_feature_streamed(imgs.to("cuda:0"), chunk=chunk)
+    assert torch.equal(got, eager) and got.shape == (B, 196, 768)
+    params = {k: v for k, v in O.synth_params(bb, O.TEACHER_SETS["dinov2"], 0).items() if k.startswith("backbone.")}
+    torch.set_num_threads(max(1, min(32, __import__("os").cpu_count() or 1)))
+    with torch.no_grad():
+        ref = O.forward_feature(params, imgs[:12], bb)
+    a, b = got[:12].float().cpu().reshape(-1).double(), ref.reshape(-1).double()
+    assert float((a - b).abs().max() / b.abs().max()) < 2e-2
+    assert float((a @ b) / (a.norm() * b.norm())) > 0.9995
+
+
+def test_streamed_call_right_behind_an_optimizer_step():
+    """The capture path (warm-up forwards + graph capture on a private stream) must be ordered behind work still queued on the
+    caller's stream: an optimizer step is enqueued and the streamed call follows WITHOUT a host synchronisation; the features must be
+    those of the updated parameters (a capture that ran ahead would cache operands built from half-updated weights)."""
+    from theia_amd.optimizers import FusedAdamW
+    from theia_amd.foundation_models.common import get_model_feature_size
+    from theia_amd.models.rvfm import RobotVisionFM
+    bb, teachers = "facebook/deit-tiny-patch16-224", O.TEACHER_SETS["dinov2"]
+    m = RobotVisionFM(backbone=bb, translator="lconv", translator_kwargs={"hidden_size_factor": 1.0},
+                      target_feature_sizes={t: get_model_feature_size(t, keep_spatial=True) for t in teachers}, precision="bf16")
+    m.load_state_dict(O.synth_params(bb, teachers, 0))
+    m = m.to("cuda:0")
+    opt = FusedAdamW(m, lr=5e-2, weight_decay=0.0)
+    imgs = O.synth_images(24, 5).to("cuda:0")
+    targets = {t: v.to("cuda:0") for t, v in O.synth_targets(24, teachers, 1).items()}
+    for _ in range(3):
+        opt.zero_grad()
+        losses = m.get_loss(m(imgs), targets, as_float=False)
+        (0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]).backward()
+        opt.step()
+        got = m.forward_feature_streamed(imgs, chunk=8)  # no synchronisation in between
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            ref = m.forward_feature(imgs)
+        assert torch.equal(got, ref)

@@ -188,3 +188,61 @@ def test_fp8_training_follows_the_bf16_loss_trajectory(tmp_path):
     assert len(a) == len(b_) == 8 and b_[-1] < b_[0] - 0.05, (a, b_)
     for x, y in zip(a, b_):
         assert abs(x - y) <= 0.10 * abs(x), (a, b_)
+
+
+def test_fused_global_norm_clip_matches_torch_clip():
+    """training.grad_clip (train_rvfm.py:126-130): FusedAdamW.clip_grad_norm_ (norm + factor on the device, applied inside the AdamW
+    kernel) against nn.utils.clip_grad_norm_ + torch.optim.AdamW, with a max_norm small enough that every step clips."""
+    from theia_amd.optimizers import FusedAdamW, param_groups_weight_decay
+    ma, teachers = _build()
+    mb, _ = _build()
+    images = O.synth_images(2, 0)
+    targets = {t: v.to("cuda:0") for t, v in O.synth_targets(2, teachers, 1).items()}
+    oa = FusedAdamW(ma, lr=1e-3, weight_decay=0.01)
+    ob = torch.optim.AdamW(param_groups_weight_decay(mb, 0.01), lr=1e-3, betas=(0.9, 0.999))
+    for step in range(3):
+        norms = []
+        for m, o in ((ma, oa), (mb, ob)):
+            o.zero_grad()
+            losses = m.get_loss(m(images), targets, as_float=False)
+            (0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]).backward()
+            max_norm = 0.05 if step < 2 else 1e6  # the last step does not clip: factor 1
+            n = o.clip_grad_norm_(max_norm) if m is ma else torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm)
+            norms.append(float(n))
+            o.step()
+        assert abs(norms[0] - norms[1]) < 1e-4 * norms[1] and (norms[1] > 0.05), norms
+        pb = dict(mb.named_parameters())
+        for k, p in ma.named_parameters():
+            if "k_proj.bias" in k:  # zero-gradient parameter: Adam normalises pure rounding noise, not comparable
+                continue
+            if step == 0:  # one clipped update from identical states: the same to the last bit or two
+                assert torch.allclose(p, pb[k], rtol=0, atol=1e-6), k
+            else:  # later steps: Adam's normalisation amplifies the last-bit differences of near-zero gradient entries
+                bad = float(((p - pb[k]).abs() > 2e-5 + 2e-3 * pb[k].abs()).float().mean())
+                assert bad < 2e-2 and float((p - pb[k]).abs().max()) < 3e-3, (k, bad)
+    assert oa._clip is None  # consumed by step()
+
+
+def test_train_script_with_grad_clip(tmp_path):
+    """training.grad_clip=true keeps the fused optimizer (it used to fall back to torch.optim.AdamW + clip_grad_norm_)"""
+    from theia_amd.scripts.train import train_rvfm
+    from theia_amd.optimizers import FusedAdamW
+    seen = []
+    orig = FusedAdamW.clip_grad_norm_
+
+    def spy(self, max_norm):
+        seen.append(max_norm)
+        return orig(self, max_norm)
+
+    FusedAdamW.clip_grad_norm_ = spy
+    try:
+        hist = train_rvfm.main([
+            "dataset=synthetic", "training/target_models=dinov2", "training.grad_clip=true",
+            "model.backbone.backbone=facebook/deit-tiny-patch16-224", "training.batch_size=4", "training.epochs=1",
+            "dataset.train_steps_per_epoch=10", "dataset.eval_steps_per_epoch=1", "training.base_lr=0.02", "+dataset.fixed_batch=true",
+            "precision=bf16", f"logging.model_path={tmp_path}", "+logging.log_interval=5",
+        ])
+    finally:
+        FusedAdamW.clip_grad_norm_ = orig
+    tl = [v for _, v in hist["train_main_loss"]]
+    assert len(seen) == 10 and len(tl) == 2 and all(v == v for v in tl) and tl[-1] < tl[0]

@@ -52,6 +52,28 @@ extern "C" int theia_cast(const float* src, void* dst, int64_t n, int dtype, voi
     return THEIA_OK;
 }
 
+// dst[i] = float(src[i]) * scale: widening of a bf16 gradient-exchange buffer back into the fp32 bucket (theia_amd/parallel.py)
+__global__ void upcast_scale_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n, float scale) {
+    const int64_t n8 = n / 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8];
+        load8(src + i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= scale;
+        store8(dst + i * 8, v);
+    }
+    for (int64_t i = n8 * 8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = bf16_to_f32(src[i]) * scale;
+}
+extern "C" int theia_upcast_scale_bf16(const void* src_bf16, float* dst, int64_t n, float scale, void* stream) {
+    THEIA_CHECK_ARG(src_bf16 && dst && n > 0 && (reinterpret_cast<uintptr_t>(src_bf16) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
+                    "theia_upcast_scale_bf16: bad args (16-byte aligned buffers)");
+    hipLaunchKernelGGL(upcast_scale_kernel, dim3(grid_for(n / 8 + 1, 256, 8192)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const bf16_t*)src_bf16, dst, n, scale);
+    THEIA_CHECK_LAUNCH("theia_upcast_scale_bf16");
+    return THEIA_OK;
+}
+
 template <typename T>
 __global__ void cast_transpose_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int C, int64_t ldd) {
     __shared__ float tile[32][33];
@@ -307,8 +329,11 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* __restrict__
         uint32_t lo = 0, hi = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            am = fmaxf(am, fabsf(x[j]));
-            x[j] = fminf(fmaxf(x[j] * sc, -448.f), 448.f);  // e4m3fn has no infinity: saturate
+            // NaN / Inf must show up, not be clamped away (fmaxf drops a NaN operand): a non-finite input makes the recorded maximum
+            // +Inf (the scale update then leaves the scale alone) and a NaN stays a NaN in e4m3fn, so the GEMM output carries it
+            const bool nan = x[j] != x[j];
+            am = nan ? INFINITY : fmaxf(am, fabsf(x[j]));
+            x[j] = nan ? x[j] : fminf(fmaxf(x[j] * sc, -448.f), 448.f);  // e4m3fn has no infinity: saturate
         }
         lo = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], lo, false);
         lo = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], lo, true);
@@ -936,7 +961,9 @@ extern "C" int theia_scatter_tokens(const void* src, void* dst, int b, int nsrc,
 // fused AdamW over a flat f32 range (torch.optim.AdamW semantics: decoupled decay applied first)
 // ------------------------------------------------------------------------------------------------
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                             int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gscale) {
+                             int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gscale,
+                             const float* __restrict__ gscale_dev) {
+    if (gscale_dev != nullptr) gscale *= *gscale_dev;  // clip coefficient computed on the device (theia_grad_clip_coef)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         float pi = p[i] * (1.0f - lr * wd);
@@ -953,8 +980,68 @@ extern "C" int theia_adamw_step(float* p, const float* g, float* m, float* v, in
                                 float eps, float weight_decay, float bias_c1, float bias_c2, float grad_scale, void* stream) {
     THEIA_CHECK_ARG(p && g && m && v && n > 0, "theia_adamw_step: bad args");
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n, lr,
-                       beta1, beta2, eps, weight_decay, bias_c1, bias_c2, grad_scale);
+                       beta1, beta2, eps, weight_decay, bias_c1, bias_c2, grad_scale, (const float*)nullptr);
     THEIA_CHECK_LAUNCH("theia_adamw_step");
+    return THEIA_OK;
+}
+extern "C" int theia_adamw_step_scaled(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                       float eps, float weight_decay, float bias_c1, float bias_c2, const float* grad_scale_dev, void* stream) {
+    THEIA_CHECK_ARG(p && g && m && v && n > 0 && grad_scale_dev, "theia_adamw_step_scaled: bad args");
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n, lr,
+                       beta1, beta2, eps, weight_decay, bias_c1, bias_c2, 1.0f, grad_scale_dev);
+    THEIA_CHECK_LAUNCH("theia_adamw_step_scaled");
+    return THEIA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// global-norm gradient clipping over the flat gradient buckets (nn.utils.clip_grad_norm_, train_rvfm.py:126-130) without a host
+// round trip: per-range partial sums of squares in a fixed order (bit-reproducible), one finalize block -> (total norm, coefficient)
+// ------------------------------------------------------------------------------------------------
+constexpr int SUMSQ_BLOCKS = 256;
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partials) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
+        const float v = g[n4 * 4 + threadIdx.x];
+        s += v * v;
+    }
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+extern "C" int theia_grad_sumsq_blocks(void) { return SUMSQ_BLOCKS; }
+extern "C" int theia_grad_sumsq(const float* g, int64_t n, float* partials, void* stream) {
+    THEIA_CHECK_ARG(g && partials && n > 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "theia_grad_sumsq: bad args (16-byte aligned range)");
+    hipLaunchKernelGGL(grad_sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, n, partials);
+    THEIA_CHECK_LAUNCH("theia_grad_sumsq");
+    return THEIA_OK;
+}
+// out[0] = sqrt(sum of partials), out[1] = min(1, max_norm / (out[0] + 1e-6))  (torch's clip coefficient)
+__global__ __launch_bounds__(256) void grad_clip_coef_kernel(const float* __restrict__ partials, int nparts, float max_norm, float* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += (double)partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float total = (float)sqrt(red[0]);
+        out[0] = total;
+        const float c = max_norm / (total + 1e-6f);
+        out[1] = c < 1.0f ? c : 1.0f;
+    }
+}
+extern "C" int theia_grad_clip_coef(const float* partials, int nparts, float max_norm, float* out2, void* stream) {
+    THEIA_CHECK_ARG(partials && out2 && nparts > 0 && max_norm > 0.f, "theia_grad_clip_coef: bad args");
+    hipLaunchKernelGGL(grad_clip_coef_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partials, nparts, max_norm, out2);
+    THEIA_CHECK_LAUNCH("theia_grad_clip_coef");
     return THEIA_OK;
 }
 

@@ -518,6 +518,10 @@ class StudentEngine:
         params = list(vit.parameters())
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _BackboneFn.apply(self, img, channels_last, do_rescale, do_normalize, geo, *params)
+        if self.fp8 is not None:
+            # delayed scaling outside training: the scales are otherwise refreshed only when the operand cache is rebuilt after an
+            # optimizer step, so an inference / eval loop would keep the activation scales of its first batch for ever
+            self.fp8.update()
         z, _ = self._backbone_fwd(img, channels_last, do_rescale, do_normalize, save=False, geo=geo)
         return z
 
@@ -623,10 +627,7 @@ class StudentEngine:
             side.run(lambda: ops.linear_wgrad(dy, x, gw_, accw_, side.ws, bias=(gb_, accb_)), dy, x)
 
         hL, meanf, rstdf = saved["final"]
-        gw, accw = self._grad(vit.layernorm.weight)
-        gb, accb = self._grad(vit.layernorm.bias)
-        assert accw == accb
-        dh = ops.layernorm_bwd(dz, hL, vit.layernorm.weight, meanf, rstdf, None, gw, gb, accw, ws)
+        dh = self._ln_bwd(dz, hL, vit.layernorm, meanf, rstdf, None, ws)
         vit_buckets = [bk for bk in self.buckets if bk.name.startswith("vit:")]  # layer groups 9-11, 6-8, 3-5, 0-2
         group_lo = {9: vit_buckets[0], 6: vit_buckets[1], 3: vit_buckets[2]}
         for i in range(NUM_LAYERS - 1, -1, -1):
@@ -640,9 +641,7 @@ class StudentEngine:
             wgrad(dpre, m, L.mlp.fc1.weight, L.mlp.fc1.bias)
             dm = self._mm(dpre, f"l{i}.w1T")
             del dpre
-            g2w, acc = self._grad(L.layernorm_after.weight)
-            g2b, _ = self._grad(L.layernorm_after.bias)
-            dh1 = ops.layernorm_bwd(dm, h1, L.layernorm_after.weight, mean2, rstd2, dh, g2w, g2b, acc, ws)
+            dh1 = self._ln_bwd(dm, h1, L.layernorm_after, mean2, rstd2, dh, ws)
             del dm, dh
             # h1 = h + o_proj(o)
             wgrad(dh1, o, L.attention.o_proj.weight, L.attention.o_proj.bias)
@@ -656,9 +655,7 @@ class StudentEngine:
                     wgrad(sl, a, prj.weight, prj.bias)
             da = self._mm(dqkv, f"l{i}.wqkvT")
             del dqkv
-            g1w, acc = self._grad(L.layernorm_before.weight)
-            g1b, _ = self._grad(L.layernorm_before.bias)
-            dh = ops.layernorm_bwd(da, h, L.layernorm_before.weight, mean1, rstd1, dh1, g1w, g1b, acc, ws)
+            dh = self._ln_bwd(da, h, L.layernorm_before, mean1, rstd1, dh1, ws)
             del da, dh1
             if i in group_lo:
                 self._bucket_done(group_lo[i], side)
@@ -708,6 +705,17 @@ class StudentEngine:
         ops.wgrad_finish(slabs, splits, D, 1, 768, gpw, 768, 0, 1, acc)
         self._bucket_done(vit_buckets[3], side)
 
+    def _ln_bwd(self, dy, x, ln, mean, rstd, dresid, ws):
+        """row-LayerNorm backward with the affine gradients written to the bucket.  The kernel takes ONE accumulate flag for weight and
+        bias; when the two parameters disagree (one frozen, or only one of the .grad tensors reset to None under gradient
+        accumulation) the slot that must NOT accumulate is zeroed first and the kernel accumulates into both."""
+        gw, accw = self._grad(ln.weight)
+        gb, accb = self._grad(ln.bias)
+        if accw != accb:
+            ops.fill_zero(gw if not accw else gb)
+            accw = accb = True
+        return ops.layernorm_bwd(dy, x, ln.weight, mean, rstd, dresid, gw, gb, accw, ws)
+
     def _wgrad_qkv_fused(self, dqkv: torch.Tensor, a: torch.Tensor, mods, side: "_SideQueue") -> bool:
         """The q / k / v weight and bias gradients as ONE [3D, D] weight-gradient GEMM when their slots in the flat gradient bucket
         are adjacent (they are: consecutive parameters of one layer, D*D and D multiples of 8): 27 output tiles x 9 row splits
@@ -718,14 +726,29 @@ class StudentEngine:
         ws_, bs_ = [m.weight for m in mods], [m.bias for m in mods]
         if not all(p.requires_grad for p in ws_ + bs_) or os.environ.get("THEIA_QKV_WGRAD") == "split":
             return False
+        # the bail-out checks must not touch p.grad (self._grad makes it the bucket view: a fallback that called it again would see
+        # "gradient present" and accumulate onto stale bucket contents): inspect the bucket slots and the .grad state directly
+        def slot(p):
+            b, i = self._bucket_of[id(p)]
+            return b, b.offsets[i]
+
+        def will_accumulate(p):
+            return p.grad is not None
+
+        if len({will_accumulate(p) for p in ws_ + bs_}) != 1:
+            return False
+        for lst, n in ((ws_, D * D), (bs_, D)):
+            for p0, p1 in zip(lst, lst[1:]):
+                (b0, o0), (b1, o1) = slot(p0), slot(p1)
+                if b0 is not b1 or o1 != o0 + n:
+                    return False
+            for p in lst:  # a foreign .grad tensor (not the bucket view) would need the copy self._grad does: take the slow path
+                if p.grad is not None:
+                    b, o = slot(p)
+                    if b.flat is None or p.grad.data_ptr() != b.flat.data_ptr() + 4 * o:
+                        return False
         gw = [self._grad(p) for p in ws_]
         gb = [self._grad(p) for p in bs_]
-        if len({acc for _g, acc in gw + gb}) != 1:
-            return False
-        for lst, n in ((gw, D * D), (gb, D)):
-            for (g0, _a0), (g1, _a1) in zip(lst, lst[1:]):
-                if g1.data_ptr() != g0.data_ptr() + 4 * n:
-                    return False
         acc = gw[0][1]
         gw_all = torch.as_strided(gw[0][0], (3 * D, D), (D, 1))   # views over the three adjacent bucket slots
         gb_all = torch.as_strided(gb[0][0], (3 * D,), (1,))

@@ -36,7 +36,7 @@ def _read_weights(path: str) -> Dict[str, torch.Tensor]:
     if path.endswith(".safetensors"):
         from safetensors.torch import load_file
         return load_file(path)
-    return torch.load(path, map_location="cpu")
+    return torch.load(path, map_location="cpu", weights_only=True)  # hub-sourced pickle: tensors only
 
 
 def _target_sizes(cfg: Dict[str, Any]) -> Optional[Dict[str, tuple]]:
@@ -90,6 +90,16 @@ class TheiaModel(RobotVisionFM):
             if k2 in own:  # rvfm.py:84-86: keep the keys the model has
                 picked[k2] = v
         missing = [k for k in own if k not in picked]
+        # a snapshot whose keys map to nothing (another prefix, an unknown legacy naming) would otherwise leave a randomly initialised
+        # model behind without a word
+        if not picked:
+            raise RuntimeError(f"{wfile}: none of its {len(weights)} tensors matches a parameter of the model "
+                               f"(first keys: {list(weights)[:3]}; expected e.g. {list(own)[:2]})")
+        missing_backbone = [k for k in missing if k.startswith("backbone.")]
+        if missing_backbone:
+            import warnings
+            warnings.warn(f"{wfile}: {len(missing_backbone)} backbone tensors are not in the checkpoint and keep their initial values "
+                          f"(e.g. {missing_backbone[:3]})")
         model.load_state_dict(picked, strict=False)
         model.loading_info = {"loaded": len(picked), "missing_keys": missing, "unexpected_keys": len(weights) - len(picked)}
         return model.to(device) if device else model

@@ -324,6 +324,13 @@ def cast(src: torch.Tensor, dst: torch.Tensor) -> None:
     N.check(N.lib().theia_cast(src.data_ptr(), dst.data_ptr(), src.numel(), _dt(dst), N.stream_ptr()), "theia_cast")
 
 
+def upcast_scale(src_bf16: torch.Tensor, dst_f32: torch.Tensor, scale: float = 1.0) -> None:
+    """dst = float(src) * scale (flat buffers)"""
+    assert src_bf16.dtype == torch.bfloat16 and dst_f32.dtype == torch.float32 and src_bf16.numel() == dst_f32.numel()
+    N.check(N.lib().theia_upcast_scale_bf16(src_bf16.data_ptr(), dst_f32.data_ptr(), dst_f32.numel(), float(scale), N.stream_ptr()),
+            "theia_upcast_scale_bf16")
+
+
 def cast_transpose(src: torch.Tensor, dst: torch.Tensor, ldd: Optional[int] = None) -> None:
     R, Cc = src.shape
     N.check(N.lib().theia_cast_transpose(src.data_ptr(), dst.data_ptr(), R, Cc, ldd or R, _dt(dst), N.stream_ptr()),
@@ -566,6 +573,25 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step: int, grad_scale: flo
     bc2 = 1.0 - beta2 ** step
     N.check(N.lib().theia_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps, wd,
                                      bc1, bc2, grad_scale, N.stream_ptr()), "theia_adamw_step")
+
+
+def adamw_step_scaled(p, g, m, v, lr, beta1, beta2, eps, wd, step: int, grad_scale_dev: torch.Tensor) -> None:
+    """adamw_step with the gradient scale read from a 1-element device tensor (the clip coefficient)"""
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    N.check(N.lib().theia_adamw_step_scaled(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps, wd,
+                                            bc1, bc2, grad_scale_dev.data_ptr(), N.stream_ptr()), "theia_adamw_step_scaled")
+
+
+def grad_sumsq(g: torch.Tensor, partials: torch.Tensor) -> None:
+    """partials[:theia_grad_sumsq_blocks()] = partial sums of squares of the flat f32 range g"""
+    N.check(N.lib().theia_grad_sumsq(g.data_ptr(), g.numel(), partials.data_ptr(), N.stream_ptr()), "theia_grad_sumsq")
+
+
+def grad_clip_coef(partials: torch.Tensor, max_norm: float, out2: torch.Tensor) -> None:
+    """out2 = (total norm, min(1, max_norm / (total + 1e-6)))"""
+    N.check(N.lib().theia_grad_clip_coef(partials.data_ptr(), partials.numel(), float(max_norm), out2.data_ptr(), N.stream_ptr()),
+            "theia_grad_clip_coef")
 
 
 def probe_tr16(image: torch.Tensor, addr: torch.Tensor) -> torch.Tensor:

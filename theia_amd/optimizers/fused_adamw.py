@@ -26,6 +26,7 @@ class FusedAdamW(torch.optim.Optimizer):
         params = [p for b in self.engine.buckets for p in b.params]
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.step_count = 0
+        self._clip = None  # (norm, coefficient) device pair set by clip_grad_norm_ and consumed by the next step()
         self.flat_state = []
         for b in self.engine.buckets:
             dev = b.params[0].device
@@ -74,19 +75,52 @@ class FusedAdamW(torch.optim.Optimizer):
             runs.append((cur[0], cur[1]))
         return runs
 
+    def _live_runs(self):
+        """(bucket, state, lo, hi, decay?) of every maximal range of trainable parameters with a gradient, in bucket order"""
+        for b, st in zip(self.engine.buckets, self.flat_state):
+            if b.flat is None:
+                continue
+            n_dec = sum(1 for i in range(len(b.params)) if b.offsets[i] < b.decay_numel)
+            for lo, hi, decay in ((0, n_dec, True), (n_dec, len(b.params), False)):
+                for s, e in self._runs(b, lo, hi):
+                    yield b, st, s, e, decay
+
+    @torch.no_grad()
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        """``nn.utils.clip_grad_norm_`` (2-norm over every parameter with a gradient; train_rvfm.py:126-130) on the flat buckets, on
+        the device: partial sums of squares per live range (fixed order), one finalize launch -> total norm and the factor
+        min(1, max_norm / (norm + 1e-6)).  The NEXT ``step()`` multiplies every gradient with that factor inside the AdamW kernel; the
+        ``.grad`` tensors themselves stay unscaled (torch scales them in place).  Returns the total norm as a 0-d device tensor, like
+        torch does -- reading it is the caller's host synchronisation, not this function's."""
+        from .. import _native as N
+        runs = list(self._live_runs())
+        dev = self.flat_state[0]["p"].device
+        nb = N.lib().theia_grad_sumsq_blocks()
+        out = torch.zeros(2, dtype=torch.float32, device=dev)
+        if not runs:
+            out[1] = 1.0
+            self._clip = out
+            return out[0]
+        partials = torch.empty(len(runs) * nb, dtype=torch.float32, device=dev)
+        for i, (b, _st, s, e, _d) in enumerate(runs):
+            ops.grad_sumsq(b.flat[s:e], partials[i * nb:(i + 1) * nb])
+        ops.grad_clip_coef(partials, max_norm, out)
+        self._clip = out
+        return out[0]
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         self.step_count += 1
         g = self.param_groups[0]
         lr, (b1, b2), eps, wd = g["lr"], g["betas"], g["eps"], g["weight_decay"]
-        for b, st in zip(self.engine.buckets, self.flat_state):
-            if b.flat is None:
-                continue
-            n_dec = sum(1 for i in range(len(b.params)) if b.offsets[i] < b.decay_numel)
-            for lo, hi, decay in ((0, n_dec, wd), (n_dec, len(b.params), 0.0)):
-                for s, e in self._runs(b, lo, hi):
-                    ops.adamw_step(st["p"][s:e], b.flat[s:e], st["m"][s:e], st["v"][s:e], lr, b1, b2, eps, decay, self.step_count)
+        clip, self._clip = self._clip, None
+        for b, st, s, e, decay in self._live_runs():
+            if clip is None:
+                ops.adamw_step(st["p"][s:e], b.flat[s:e], st["m"][s:e], st["v"][s:e], lr, b1, b2, eps, wd if decay else 0.0, self.step_count)
+            else:
+                ops.adamw_step_scaled(st["p"][s:e], b.flat[s:e], st["m"][s:e], st["v"][s:e], lr, b1, b2, eps, wd if decay else 0.0,
+                                      self.step_count, clip[1:2])
         _engine_mod.PARAM_EPOCH[0] += 1
         return loss
 

@@ -19,24 +19,90 @@ import torch
 import torch.distributed as dist
 
 
-class GradBucketReducer:
-    """Average flat gradient buckets across ranks, asynchronously, in the order they become ready."""
+def configure_rccl_env() -> None:
+    """Environment RCCL reads when the communicator is created -- call before ``init_process_group``.
 
-    def __init__(self, process_group=None):
+    ``THEIA_RCCL_MAX_NCHANNELS=<n>`` caps the number of channels (= workgroups) RCCL runs a collective with (``NCCL_MAX_NCHANNELS``):
+    the bucket all-reduces overlap the data-gradient GEMMs, whose persistent kernel wants every CU (one 147 KB-LDS workgroup each);
+    an all-reduce that takes fewer CUs for longer can be the better trade on xGMI, where a ring is bound per link (~153 GB/s), not
+    by how many CUs copy."""
+    n = os.environ.get("THEIA_RCCL_MAX_NCHANNELS")
+    if n:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(int(n)))
+
+
+class GradBucketReducer:
+    """Average flat gradient buckets across ranks, asynchronously, in the order they become ready.
+
+    exchange:   "allreduce" (default) -- one all-reduce (AVG) per bucket;
+                "rs_ag" -- reduce-scatter (AVG) into this rank's 1/world shard of the bucket, then all-gather, both in place on the
+                flat buffer (what a ring all-reduce does internally; as two collectives the shard is available in between -- the hook a
+                sharded optimizer step would use -- and the all-gather can trail the next bucket's reduce-scatter);
+    comm_dtype: "fp32" (default) or "bf16" -- the bucket is rounded to bf16 for the exchange (half the bytes on the xGMI links: 376
+                instead of 752 MB per step for DeiT-base + 5 teachers) and widened back into the fp32 bucket afterwards.
+    Environment: THEIA_DP_EXCHANGE, THEIA_DP_COMM_DTYPE."""
+
+    def __init__(self, process_group=None, exchange: Optional[str] = None, comm_dtype: Optional[str] = None):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.exchange = exchange or os.environ.get("THEIA_DP_EXCHANGE", "allreduce")
+        self.comm_dtype = comm_dtype or os.environ.get("THEIA_DP_COMM_DTYPE", "fp32")
+        if self.exchange not in ("allreduce", "rs_ag") or self.comm_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"GradBucketReducer: exchange={self.exchange!r} comm_dtype={self.comm_dtype!r}")
         self._pending: List = []
         self._side: Optional[torch.cuda.Stream] = None
+        self._stage: dict = {}  # bf16 staging buffers, one per bucket (keyed by the flat buffer's address)
+
+    # ------------------------------------------------------------------ the exchange itself (on whatever stream is current)
+    def _exchange(self, buf: torch.Tensor, avg: bool):
+        """all-reduce `buf` (SUM or AVG) with the configured collective(s); returns the last work handle (or None)"""
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        async_ok = avg or not buf.is_cuda or os.environ.get("THEIA_GLOO_ASYNC") == "1"
+        if self.exchange == "rs_ag" and buf.numel() % self.world == 0:
+            shards = buf.view(self.world, -1)
+            mine = shards[self.rank]
+            if dist.get_backend(self.pg) == "nccl":
+                dist.reduce_scatter_tensor(mine, buf, op=op, group=self.pg, async_op=False)  # in place: output = input shard `rank`
+                return dist.all_gather_into_tensor(buf, mine, group=self.pg, async_op=True)
+            # gloo (CPU tests) has no reduce-scatter: one reduce per shard to its owner, then the all-gather
+            for r in range(self.world):
+                dist.reduce(shards[r], dst=r, op=op, group=self.pg)
+            return dist.all_gather_into_tensor(buf, mine.clone(), group=self.pg, async_op=async_ok)
+        return dist.all_reduce(buf, op=op, group=self.pg, async_op=async_ok)
+
+    def _reduce(self, flat: torch.Tensor, avg: bool):
+        """-> (work, post) ; post() finishes the bucket once work is done (widening / scaling)"""
+        scale = 1.0 if avg else 1.0 / self.world
+        if self.comm_dtype == "bf16":
+            st = self._stage.get(flat.data_ptr())
+            if st is None or st.numel() != flat.numel():
+                st = self._stage[flat.data_ptr()] = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+            if flat.is_cuda:
+                from . import ops
+                ops.cast(flat, st)
+            else:
+                st.copy_(flat)
+            work = self._exchange(st, avg)
+
+            def post():
+                if flat.is_cuda:
+                    from . import ops
+                    ops.upcast_scale(st, flat, scale)
+                else:
+                    flat.copy_(st.float().mul_(scale))
+            return work, post
+        work = self._exchange(flat, avg)
+        return work, (None if avg else (lambda: flat.div_(self.world)))
 
     def bucket_ready(self, flat: torch.Tensor, also_after: Optional["torch.cuda.Event"] = None) -> None:
         """flat is complete once the current stream -- and ``also_after`` (an event on another producer stream: the
-        engine's weight-gradient queue) -- have been reached; the all-reduce waits for both on its own stream."""
+        engine's weight-gradient queue) -- have been reached; the exchange waits for both on its own stream."""
         if self.world == 1:
             return
         # RCCL has an AVG reduction (no extra scale kernel); gloo (CPU tests, and the 2-ranks-on-one-GPU test) sums and
         # the result is scaled when the bucket is waited for
         avg = dist.get_backend(self.pg) == "nccl"
-        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         if flat.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=flat.device)
@@ -49,29 +115,57 @@ class GradBucketReducer:
                 # gloo stages device tensors through the host on its own pool streams; issued asynchronously from here it
                 # dead-locked sporadically in work.wait() (2 ranks sharing one GPU), so that test-only combination runs
                 # synchronously.  RCCL collectives are stream-ordered and stay asynchronous.
-                work = dist.all_reduce(flat, op=op, group=self.pg, async_op=avg or os.environ.get("THEIA_GLOO_ASYNC") == "1")
-            self._pending.append((work, flat, not avg))
+                work, post = self._reduce(flat, avg)
+                if avg and post is not None:  # RCCL + bf16 exchange: widen on the side stream, behind the collective
+                    if work is not None:
+                        work.wait()  # (stream-level: the side stream waits for RCCL's stream; the host does not block)
+                    post()
+                    work = post = None
+            self._pending.append((work, flat, post))
         else:
-            work = dist.all_reduce(flat, op=op, group=self.pg, async_op=True)
-            self._pending.append((work, flat, not avg))
+            work, post = self._reduce(flat, avg)
+            self._pending.append((work, flat, post))
 
     def finish(self) -> None:
         """Make the current stream (GPU) / the caller (CPU) wait for every outstanding bucket."""
-        for work, flat, scale in self._pending:
+        for work, flat, post in self._pending:
             if work is not None:
                 work.wait()
-            if scale:
-                flat.div_(self.world)
+            if post is not None:
+                post()
+        if self._side is not None and self._pending:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
         self._pending.clear()
 
 
-def broadcast_parameters(params, src: int = 0, process_group=None) -> None:
-    """Parameter broadcast from rank 0 at start-up (DDP constructor behaviour, train_rvfm.py:258)."""
+def broadcast_parameters(params, src: int = 0, process_group=None, bucket_bytes: int = 256 << 20) -> None:
+    """Parameter broadcast from rank 0 at start-up (DDP constructor behaviour, train_rvfm.py:258) -- coalesced: parameters are packed
+    into flat buffers of up to ``bucket_bytes`` per dtype and each buffer is ONE collective (DDP coalesces the same way; one
+    broadcast per tensor is ~230 latency-bound collectives for DeiT-base + 5 heads)."""
     if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
         return
     with torch.no_grad():
+        group: List[torch.Tensor] = []
+        size = 0
+
+        def flush():
+            nonlocal group, size
+            if not group:
+                return
+            flat = torch.cat([p.data.reshape(-1) for p in group])
+            dist.broadcast(flat, src=src, group=process_group)
+            off = 0
+            for p in group:
+                p.data.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            group, size = [], 0
+
         for p in params:
-            dist.broadcast(p.data, src=src, group=process_group)
+            if group and (p.dtype != group[0].dtype or p.device != group[0].device or size + p.numel() * p.element_size() > bucket_bytes):
+                flush()
+            group.append(p)
+            size += p.numel() * p.element_size()
+        flush()
 
 
 class TheiaDataParallel(torch.nn.Module):

@@ -117,7 +117,11 @@ def train(rvfm: nn.Module, target_model_names, optimizer, lr_scheduler, train_it
             optimizer.zero_grad()
             main_loss.backward()
             if cfg.training.grad_clip:
-                nn.utils.clip_grad_norm_(rvfm.parameters(), cfg.training.grad_clip_norm_warmup if steps < warmup_steps else cfg.training.grad_clip_norm)
+                max_norm = cfg.training.grad_clip_norm_warmup if steps < warmup_steps else cfg.training.grad_clip_norm
+                if isinstance(optimizer, FusedAdamW):  # global norm + clip factor on the device, applied inside the AdamW kernel
+                    optimizer.clip_grad_norm_(max_norm)
+                else:
+                    nn.utils.clip_grad_norm_(rvfm.parameters(), max_norm)
             optimizer.step()
             if lr_scheduler is not None:
                 lr_scheduler.step()
@@ -164,6 +168,8 @@ def save_checkpoint(model: nn.Module, cfg, steps: int) -> str:
 def ddp_setup() -> None:
     if "RANK" in os.environ and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from theia_amd.parallel import configure_rccl_env
+        configure_rccl_env()
         dist.init_process_group("nccl")  # RCCL on ROCm
 
 
@@ -209,7 +215,7 @@ def ddp_main(cfg) -> dict:
     total_train_steps = train_epoch_steps * cfg.training.epochs
 
     lr = cfg.training.base_lr * ((cfg.training.batch_size * world_size) / (cfg.training.base_batch_size * cfg.training.base_world_size))
-    if cfg.training.optimizer.get("_target_", "") in ("torch.optim.AdamW", "theia_amd.optimizers.FusedAdamW") and not cfg.training.grad_clip:
+    if cfg.training.optimizer.get("_target_", "") in ("torch.optim.AdamW", "theia_amd.optimizers.FusedAdamW"):
         # same update rule as torch.optim.AdamW, fused over the engine's flat buckets (2 HIP launches per bucket); it is a
         # torch.optim.Optimizer, so the configured LR scheduler (constant or cosine warm restarts, both behind a linear
         # warm-up: lr_schedulers.py:8-77) drives it exactly as in the reference

@@ -66,15 +66,18 @@ class StreamedForwardFeature:
         if images.dtype != torch.uint8 or images.dim() != 4:
             raise TypeError("StreamedForwardFeature takes a uint8 [B, H, W, 3] / [B, 3, H, W] tensor")
         B = images.shape[0]
+        # Everything below runs on the private streams: order them behind the caller's stream FIRST -- the capture path (two eager
+        # warm-up forwards + the graph capture on `compute`) rebuilds the engine's operand cache from the parameters and uses its
+        # shared workspace, so it must not start while an optimizer step / backward is still queued on the caller's stream.
+        cur = torch.cuda.current_stream(self.device)
+        self.compute.wait_stream(cur)
+        self.copy.wait_stream(cur)
         g, x_static, y_static = self._captured(tuple(images.shape[1:]))
         out_shape = (B,) + tuple(y_static.shape[1:])
         if out is None:
             out = torch.empty(out_shape, dtype=y_static.dtype, device=self.device)
         elif tuple(out.shape) != out_shape or out.dtype != y_static.dtype or out.device != self.device:
             raise ValueError(f"out must be {out_shape} {y_static.dtype} on {self.device}")
-        cur = torch.cuda.current_stream(self.device)
-        self.compute.wait_stream(cur)  # `images` (if on the device) and `out` are ready
-        self.copy.wait_stream(cur)
         # second staging buffer: chunk i+1 is copied in while the graph reads chunk i from x_static; the graph itself always
         # reads x_static, so a staged chunk moves there with a D2D copy at the head of its replay (77 MB per 512 images)
         stage = getattr(self, "_stage", None)
