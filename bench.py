@@ -314,9 +314,9 @@ def load_traffic(pfx, workload=TRAFFIC_WORKLOAD):
         tj = json.load(open(best))
         if tj.get("_kernel_src_sha") != src_sha(NT_KERNEL_SOURCES):
             return None, os.path.basename(best) + " (stale: kernel sources changed since it was taken)"
-        key = sorted([k for k in tj if k.startswith("gemm_nt_pp_kernel") and (("bf16" in k) == (pfx == "bf16"))],
-                     key=lambda k: ("true" in k, k))  # the plain instantiation first (not the LayerNorm-sums one)
-        return (tj[key[0]]["hbm_bytes_per_launch"] if key else None), os.path.basename(best)
+        want = {"bf16": "gemm_nt_pp_kernel<bf16, *> (all instantiations)", "f32": "gemm_nt_pp_kernel<float, *> (all instantiations)",
+                "fp8": "gemm_nt_pp_kernel<fp8_t, *> (all instantiations)"}[pfx]
+        return (tj[want]["hbm_bytes_per_launch"] if want in tj else None), os.path.basename(best)
     except Exception:  # a malformed summary must not break the benchmark
         return None, None
 

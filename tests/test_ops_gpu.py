@@ -371,6 +371,47 @@ def test_pingpong_matches_2stage_up_to_rare_ulp_flips():
                 close(y, ys[128128][i], (kind, i, tile))
 
 
+def test_conv_kernel_column_split_at_bench_size():
+    """The 3x3 convolution kernel at the bench's own size (128 images x 768 channels: 384 tiles of 256 columns = 1.5 rounds of the
+    chip), where its launcher splits the columns into 256 full tiles + 256 tiles of 128 columns (gemm_conv_pp_kernel<.., 128>):
+    forward with ReLU + LayerNorm statistics and the data-gradient with an in-place residual, against the 2-stage 128x128 kernel on
+    the same operands (different tap order in the f32 sums: single-ulp differences in a small fraction of the elements)."""
+    from theia_amd import ops, _native as Nn
+    dev = _dev()
+    dt = torch.bfloat16
+    torch.manual_seed(3)
+    C, b = 768, 128
+    plan = ops.plan_conv3x3(C, 16)
+    (fmap, mpi), = plan.fwd
+    x = torch.randn(b, 256 * C, device=dev).to(dt)
+    W = (torch.randn(C, 9 * C, device=dev) / math.sqrt(9 * C)).to(dt)
+    bias = torch.randn(C, device=dev) * 0.1
+    assert ops.gemm_nt(x, W, x, b * mpi, C, 9 * C, fmap, 9 * C, C, plan_only=True) == 256009
+
+    def close(a, ref, what, frac_max):
+        a32, r32 = a.float(), ref.float()
+        frac = float((a32 != r32).float().mean())
+        ulp = torch.maximum(a32.abs(), r32.abs()) * 2.0 ** -7 + 1e-5 * float(r32.abs().max())
+        worst = float(((a32 - r32).abs() / ulp).max())
+        assert frac < frac_max and worst <= 1.0 + 1e-6, (what, frac, worst)
+
+    outs, sums = {}, {}
+    for tile in (128128, 256009):
+        outs[tile] = torch.zeros(b, 256 * C, dtype=dt, device=dev)
+        sums[tile] = torch.zeros(b, 2, dtype=torch.int64, device=dev)
+        ops.gemm_nt(x, W, outs[tile], b * mpi, C, 9 * C, fmap, 9 * C, C, bias=bias, act=Nn.ACT_RELU, tile=tile, ln_sums=sums[tile])
+    close(outs[256009], outs[128128], "conv fwd", 2e-3)
+    assert relerr(sums[256009].double(), sums[128128].double()) < 1e-5
+    dmap, mpi = plan.dgrad
+    gy = torch.randn(b, 256 * C, device=dev).to(dt)
+    acc0 = torch.randn(b, 256 * C, device=dev).to(dt)
+    res = {}
+    for tile in (128128, 256009):
+        res[tile] = acc0.clone()
+        ops.gemm_nt(gy, W, res[tile], b * mpi, C, 9 * C, dmap, 9 * C, C, resid=res[tile], tile=tile)
+    close(res[256009], res[128128], "conv dgrad + residual", 2e-3)
+
+
 def test_forced_tile_is_refused_not_replaced():
     """A 256256 request the ping-pong kernel cannot take is an error (never a silent fall-back to another kernel)."""
     from theia_amd import ops, _native as Nn

@@ -33,14 +33,19 @@ struct conv_taps_t {
 
 __device__ __forceinline__ int cv_f(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
-template <typename T, bool SUMS = false>
+// BN: output columns per tile, 256 or 128.  The 128-wide instantiation exists for the launcher's column split (see
+// theia_gemm_conv_pp_launch): 128 images x 768 columns are 384 tiles of 256 = 1.5 rounds of the 256 CUs, i.e. two rounds of time; as
+// 256 tiles of 256 columns + 256 tiles of 128 columns they are one full round + one round of half tiles.
+template <typename T, bool SUMS = false, int BN = 256>
 __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args_t p, const conv_taps_t tp) {
-    constexpr int BM = 256, BN = 256, WAVES_N = 4;
+    constexpr int BM = 256, WAVES_N = 4;
     constexpr int NB = 6, PD = NB - 1;
     constexpr int HKT = 64 / (int)sizeof(T);    // channels per slice (64-byte rows)
     constexpr int EPC = 16 / (int)sizeof(T);
-    constexpr int WM = 128, WN = 64, FM = 8, FN = 4;
+    constexpr int WM = 128, WN = BN / WAVES_N, FM = 8, FN = WN / 16;
     constexpr int SRP = 128;                     // rows staged per piece (512 threads x 16 B)
+    constexpr int NPB = BN / SRP;                // LDS-DMA pieces per thread per weight tile
+    static_assert(BN == 256 || BN == 128, "weight tiles of one or two 128-row staging passes");
     constexpr int BTILE = BN * 64;
     constexpr int APAD = 32 * 64;                // 32 zero rows above and below the image: pixel rows y < 0 / y >= in_h read zeros
     constexpr int ATILE = BM * 64 + 2 * APAD;    // one image-slice buffer: [pad | 256 pixel rows | pad]
@@ -74,8 +79,8 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
     const int lchunk = st_chunk ^ cv_f(st_row);
     const int npix = mp.in_h * mp.in_w;
     const float rcp_w = 1.0f / (float)mp.in_w;
-    uint64_t a_src[2], w_src[2];
-    uint32_t w_live[2];
+    uint64_t a_src[2], w_src[NPB];
+    uint32_t w_live[NPB];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int pix = st_row + SRP * i;
@@ -84,6 +89,9 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
         const int achunk = st_chunk ^ cv_f(px);
         const uint64_t pa = reinterpret_cast<uint64_t>(A + (int64_t)img * mp.in_batch_stride + mp.in_offset + (int64_t)pix * mp.in_c + achunk * EPC);
         a_src[i] = pix < npix ? pa : 0;  // 0: the zero page, not advanced with the slice
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
         const int n = n0 + st_row + SRP * i;
         w_live[i] = n < p.N ? 0xffffffffu : 0u;
         w_src[i] = n < p.N ? reinterpret_cast<uint64_t>(W + (int64_t)n * p.ldw + lchunk * EPC) : zp;
@@ -92,7 +100,7 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
         const uint32_t off = (uint32_t)((tp.wslot[r] * mp.in_c + s * HKT) * (int)sizeof(T));
         char* dst = smem + slot * BTILE + uwave * (16 * 64);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NPB; ++i) {
             const uint64_t src = w_src[i] + (off & w_live[i]);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + i * (SRP * 64)), 16, 0, 0);
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
         const int uc = min(u, nunits - 1);
         issue_b(u, uc % 9, uc / 9);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PD - 1)) : "memory");  // image slice 0 and weight tile 0 landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB * (PD - 1)) : "memory");  // image slice 0 and weight tile 0 landed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the zero pads are written
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -161,8 +169,10 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
                 const uint32_t ab = lane_b + bslot * BTILE;
                 gt_ds_read128<0>(fb[0], ab);
                 gt_ds_read128<1024>(fb[1], ab);
-                gt_ds_read128<2048>(fb[2], ab);
-                gt_ds_read128<3072>(fb[3], ab);
+                if constexpr (FN > 2) {
+                    gt_ds_read128<2048>(fb[2 % FN], ab);
+                    gt_ds_read128<3072>(fb[3 % FN], ab);
+                }
             }
             {
                 // The wave's 8 output rows of tap (dyi, dxi) read pixel rows y0 + dyi .. y0 + dyi + 7, shifted by dx.  Row q of
@@ -184,11 +194,15 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
                 // read), so the number of LDS-DMA operations younger than a given weight tile is a compile-time constant
                 if (r == 2) issue_a(min(s + 1, nslice - 1), (s + 1) & 1);
             }
-            gt_wait_lds(fb, fa);
-            // weight tile u + 1 landed: younger than it are tiles u + 2 .. u + 5 (8 operations) and, in the five units after an
-            // image slice was queued (behind tile u_A + 5), that slice's two pieces
-            if (r >= 2 && r <= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PD - 1) + 2) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PD - 1)) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < FN; ++i) asm volatile("" : "+v"(fb[i]));
+#pragma unroll
+            for (int j = 0; j < FM; ++j) asm volatile("" : "+v"(fa[j]));
+            // weight tile u + 1 landed: younger than it are tiles u + 2 .. u + 5 (NPB operations each) and, in the five units after
+            // an image slice was queued (behind tile u_A + 5), that slice's two pieces
+            if (r >= 2 && r <= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB * (PD - 1) + 2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPB * (PD - 1)) : "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -246,29 +260,70 @@ bool theia_gemm_conv_pp_match(const theia_gemm_args_t* a, int dtype, conv_taps_t
     return true;
 }
 
+template <typename T, bool SUMS, int BN>
+static void conv_pp_launch_one(const theia_gemm_args_t& a, const conv_taps_t& tp, hipStream_t stream) {
+    constexpr int ring_bytes = 6 * BN * 64 + 2 * (256 * 64 + 2 * 32 * 64);
+    constexpr int ep_bytes = 8 * 64 * (BN / 4 + 4) * 4;
+    constexpr int lds = ring_bytes > ep_bytes ? ring_bytes : ep_bytes;
+    auto kern = gemm_conv_pp_kernel<T, SUMS, BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int tiles = (a.M / 256) * cdiv_i(a.N, BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, stream, a, tp);
+}
+
+template <int BN>
+static void conv_pp_launch_bn(const theia_gemm_args_t& a, const conv_taps_t& tp, int dtype, hipStream_t stream) {
+    const bool sums = a.ln_sums != nullptr;
+    if (dtype == THEIA_BF16 && sums) conv_pp_launch_one<bf16_t, true, BN>(a, tp, stream);
+    else if (dtype == THEIA_BF16) conv_pp_launch_one<bf16_t, false, BN>(a, tp, stream);
+    else if (sums) conv_pp_launch_one<float, true, BN>(a, tp, stream);
+    else conv_pp_launch_one<float, false, BN>(a, tp, stream);
+}
+
 int theia_gemm_conv_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t stream) {
     conv_taps_t tp;
     if (!theia_gemm_conv_pp_match(a, dtype, &tp)) {
         theia_set_error("theia_gemm_nt: the row map is not a 3x3 stride-1 convolution with one 16x16 image per 256-row tile");
         return THEIA_ERR_UNSUPPORTED;
     }
-    constexpr int ring_bytes = 6 * 256 * 64 + 2 * (256 * 64 + 2 * 32 * 64);
-    constexpr int ep_bytes = 8 * 64 * (64 + 4) * 4;
-    constexpr int lds = ring_bytes > ep_bytes ? ring_bytes : ep_bytes;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_pp_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_pp_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_pp_kernel<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_pp_kernel<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+    // Column split: when the grid of 256-column tiles ends in a round that is at most half full, the last 256 columns run as a second
+    // launch of 128-column tiles -- (tiles_n - 1) * images full tiles + 2 * images half tiles.  A half tile costs ~0.6 of a full one
+    // (its R segments carry the same image-fragment reads for half the MFMAs), so this pays when it removes a whole round:
+    // 128 images x 768 columns: 2 rounds -> 1 + 0.6.  THEIA_CONV_SPLIT=0: A/B switch.
+    static int split_ok = -1, cus = 0;
+    if (split_ok < 0) {
+        const char* e = getenv("THEIA_CONV_SPLIT");
+        split_ok = (e != nullptr && strcmp(e, "0") == 0) ? 0 : 1;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
-    const int tiles = (a->M / 256) * cdiv_i(a->N, 256);
-    const bool sums = a->ln_sums != nullptr;
-    if (dtype == THEIA_BF16 && sums) hipLaunchKernelGGL((gemm_conv_pp_kernel<bf16_t, true>), dim3(tiles), dim3(512), lds, stream, *a, tp);
-    else if (dtype == THEIA_BF16) hipLaunchKernelGGL(gemm_conv_pp_kernel<bf16_t>, dim3(tiles), dim3(512), lds, stream, *a, tp);
-    else if (sums) hipLaunchKernelGGL((gemm_conv_pp_kernel<float, true>), dim3(tiles), dim3(512), lds, stream, *a, tp);
-    else hipLaunchKernelGGL(gemm_conv_pp_kernel<float>, dim3(tiles), dim3(512), lds, stream, *a, tp);
+    const int images = a->M / 256, tn = cdiv_i(a->N, 256);
+    const long full = (long)images * tn;
+    const double cost_plain = (double)cdiv_i(full, cus);
+    const double cost_split = (double)cdiv_i((long)images * (tn - 1), cus) + 0.6 * (double)cdiv_i((long)images * 2, cus);
+    if (split_ok && tn >= 2 && a->N % 256 == 0 && cost_split < cost_plain - 0.05) {
+        theia_gemm_args_t lo = *a, hi = *a;
+        const int ncut = (tn - 1) * 256;
+        const int esz = dtype == THEIA_BF16 ? 2 : 4;
+        lo.N = ncut;
+        hi.N = 256;
+        hi.w = static_cast<const char*>(a->w) + (size_t)ncut * a->ldw * esz;
+        hi.out = static_cast<char*>(a->out) + (size_t)ncut * esz;
+        if (a->bias != nullptr) hi.bias = a->bias + ncut;
+        if (a->resid != nullptr) hi.resid = static_cast<const char*>(a->resid) + (size_t)ncut * esz;
+        if (a->aux_in != nullptr) hi.aux_in = static_cast<const char*>(a->aux_in) + (size_t)ncut * esz;
+        if (a->aux_out != nullptr) hi.aux_out = static_cast<char*>(a->aux_out) + (size_t)ncut * esz;
+        conv_pp_launch_bn<256>(lo, tp, dtype, stream);
+        THEIA_CHECK_LAUNCH("theia_gemm_nt(conv)");
+        conv_pp_launch_bn<128>(hi, tp, dtype, stream);
+        THEIA_CHECK_LAUNCH("theia_gemm_nt(conv, 128-column tiles)");
+        return THEIA_OK;
+    }
+    conv_pp_launch_bn<256>(*a, tp, dtype, stream);
     THEIA_CHECK_LAUNCH("theia_gemm_nt(conv)");
     return THEIA_OK;
 }

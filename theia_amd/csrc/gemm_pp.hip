@@ -160,31 +160,15 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         next_tap_h = hpt;
         set_tap(0);
     };
-    // issue the pieces of half-tile (pf_r, pf_h) into ring slot `slot`, then advance the stream.  Past the workgroup's last
-    // half-tile the last one is fetched again (never read; keeps the counted waits uniform)
-    // src_ptr[] always points at half-tile pf_h (inside its tap) and is advanced by one 64-byte row chunk per issue -- ONE live copy of
-    // each pointer (a base + offset form made the compiler carry an incrementing copy next to the base through the loop).
-    auto pf_issue = [&](auto CROSS_C, int slot) {
-        if constexpr (decltype(CROSS_C)::value) {  // this fetch may belong to the next tile
-            if (pf_h == nh) {  // wave-uniform
-                if (pf_r + 1 < my_tiles) {
-                    ++pf_r;
-                    pf_h = 0;
-                    setup_tile(tile_of(pf_r));
-                } else {  // past the workgroup's last half-tile: fetch it again (never read; keeps the counted waits uniform)
-                    pf_h = nh - 1;
-#pragma unroll
-                    for (int q = 0; q < LPH_FULL; ++q) src_ptr[q] -= 64;
-                }
-            }
-        }
-        if constexpr (TAPS) {
-            if (pf_h >= next_tap_h) {
-                ++cur_tap;
-                next_tap_h += hpt;
-                set_tap(cur_tap);
-            }
-        }
+    // pf_issue: the pieces of half-tile (pf_r, pf_h) into ring slot `slot`, straight from src_ptr[] -- which always points at the NEXT
+    // half-tile to fetch (inside its tap) and moves one 64-byte row chunk per issue: ONE live copy of each pointer (a base + offset form
+    // made the compiler carry an incrementing copy next to the base through the loop).
+    // pf_advance: everything that is not straight-line -- entering the next tap (multi-tap maps), the next tile (address set-up), or,
+    // past the workgroup's last half-tile, stepping back to fetch it again (never read; keeps the counted waits uniform).  It runs
+    // right AFTER an M segment: the fragment registers are dead there (56 of them in the 320-row instantiations), so the address
+    // arithmetic of a tap / tile switch has room -- inside the R segment, between the asynchronous fragment reads and their wait, it
+    // cost scratch spills (and a spilled or reused register with an LDS read in flight is garbage or a memory fault).
+    auto pf_issue = [&](int slot) {
         char* sa = smem + slot * STAGE + uwave * (16 * 64);
         char* sb = sa + BM * 64;
 #pragma unroll
@@ -196,6 +180,25 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
             src_ptr[q] += 64;
         }
         ++pf_h;
+    };
+    auto pf_advance = [&]() {
+        if (pf_h == nh) {  // wave-uniform
+            if (pf_r + 1 < my_tiles) {
+                ++pf_r;
+                pf_h = 0;
+                setup_tile(tile_of(pf_r));
+            } else {
+                pf_h = nh - 1;
+#pragma unroll
+                for (int q = 0; q < LPH_FULL; ++q) src_ptr[q] -= 64;
+            }
+        } else if constexpr (TAPS) {
+            if (pf_h >= next_tap_h) {
+                ++cur_tap;
+                next_tap_h += hpt;
+                set_tap(cur_tap);
+            }
+        }
     };
     // wait until at most `halves` half-tiles' worth of this wave's pieces are outstanding
     auto wait_halves2 = [&]() {
@@ -219,45 +222,67 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         const int frow = threadIdx.x & 15, fg = (threadIdx.x >> 4) & 3;
         gt_u32x4 brow[2][2];  // bias: 2 column groups x 8 floats
         const bool has_bias = BIAS_IN_ACC && p.bias != nullptr;
-        if constexpr (BIAS_IN_ACC) {
-            if (has_bias) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int n = n_wave0 + t * 32 + fg * 8;
-                    const float* bp = p.bias + (n < p.N ? n : 0);
-                    gd_load16(brow[t][0], bp);
-                    gd_load16(brow[t][1], bp + 4);
-                }
-            }
-            if (resid_init) {
-                const gd_rows_t rw(p);
-                int dry, drx;
-                const int64_t off_dead = rw.decode(p, 0, dry, drx);
-                gd_rows_t::cursor_t c = rw.first(p, m_wave0 + frow);
-#pragma unroll
-                for (int j = 0; j < FM; ++j) {
+        // The rows arrive by inline-asm loads (invisible to the compiler's waitcnt bookkeeping) -- and to its register allocator: between
+        // such a load and the wait that covers it, the destination registers must not be spilled or reused.  The 256-row instantiations
+        // are spill-free (tests/test_kernel_resources.py holds them to that), so their first tile requests the rows BEFORE the operand
+        // prologue and lets them land behind it; the 320-row instantiations keep a few long-lived values in scratch around tile
+        // boundaries, so there the request, the wait and the use are adjacent (a destination register reused for address arithmetic while
+        // its load was in flight was a memory fault).
+        constexpr bool EARLY_ROWS = FIRST && BM == 256;
+        // EARLY_ROWS: inline-asm loads (waited for by hand).  Otherwise ordinary loads: the compiler tracks their registers and waits
+        // (with the LDS-DMA queue in flight it waits for everything -- which this path does anyway).
+        auto row_load = [&](auto& dst, const void* ptr) {
+            if constexpr (EARLY_ROWS) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+            else dst = __builtin_bit_cast(typename std::remove_reference<decltype(dst)>::type, *reinterpret_cast<const gt_u32x4*>(ptr));
+        };
+        auto request_rows = [&]() {
+            if constexpr (BIAS_IN_ACC) {
+                if (has_bias) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const int n = n_wave0 + t * 32 + fg * 8;
-                        const bool lv = (c.m < p.M) && (n < p.N);
-                        // straight into the accumulator registers of fragment (2t, j): 8 bf16 = 4 dwords, expanded in place below
-                        // (a separate row buffer would be 16 * FM more registers alive next to the full accumulator set)
-                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(acc[2 * t][j]) : "v"(RES + (lv ? c.off + n : off_dead)) : "memory");
+                        const float* bp = p.bias + (n < p.N ? n : 0);
+                        row_load(brow[t][0], bp);
+                        row_load(brow[t][1], bp + 4);
                     }
-                    rw.next(c);
+                }
+                if (resid_init) {
+                    const gd_rows_t rw(p);
+                    int dry, drx;
+                    const int64_t off_dead = rw.decode(p, 0, dry, drx);
+                    gd_rows_t::cursor_t c = rw.first(p, m_wave0 + frow);
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const int n = n_wave0 + t * 32 + fg * 8;
+                            const bool lv = (c.m < p.M) && (n < p.N);
+                            // straight into the accumulator registers of fragment (2t, j): 8 bf16 = 4 dwords, expanded in place below
+                            // (a separate row buffer would be 16 * FM more registers alive next to the full accumulator set)
+                            row_load(acc[2 * t][j], RES + (lv ? c.off + n : off_dead));
+                        }
+                        rw.next(c);
+                    }
                 }
             }
-        }
+        };
+        if constexpr (EARLY_ROWS) request_rows();
         if constexpr (FIRST) {
             setup_tile(tile_id);
             PP_PHASE(1)
 #pragma unroll
-            for (int s = 0; s < NSTAGE - 1; ++s) pf_issue(std::true_type{}, s);
+            for (int s = 0; s < NSTAGE - 1; ++s) {
+                pf_issue(s);
+                pf_advance();
+            }
             PP_PHASE(2)
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (EARLY_ROWS) {  // loads retire in order: the rows have landed once only the prologue's pieces are outstanding
             if (A_TAIL_WAVES != 0 && !tailw) pp_wait_vm<3 * LPH_PART>();
             else pp_wait_vm<3 * LPH_FULL>();
         } else {
+            request_rows();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if constexpr (BIAS_IN_ACC) {
@@ -321,6 +346,23 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
     gt_u32x4 fb[FN], fa[FM];
     int g = 0;  // global half-tile counter of this workgroup: ring slot = g & 3
 
+    // Tile boundaries: the groups re-join (group 0 executes one barrier more), run their epilogues CONCURRENTLY (one group's
+    // conversions overlap the other's store issue: serialised -- group 0's epilogue beside group 1's last M segment and vice versa, no
+    // re-join -- the two epilogues took 9.6k + 10k cycles instead of 14.5k together, measured), and stagger again.  What the boundary
+    // does NOT do any more is drain the memory queue:
+    //  * the ring invariant carries over (slot = g & 3 with g running across tiles; half-tile g+1 has been waited for and fenced by
+    //    the barrier at the end of R(g), whichever tile it belongs to);
+    //  * the epilogue's stores stay in flight into the next loop.  That is legal for the loop's counted waits: vmcnt(N) guarantees
+    //    that at most N operations are outstanding, loads retire in order among themselves, so "the pieces of half-tile g+1 have
+    //    landed" follows whatever the stores do -- a store still in flight only makes the wait stricter (it can never be satisfied by
+    //    loads that have not retired).  What is NOT legal is waiting for loads issued after stores with a non-zero count; the only
+    //    such loads are a next tile's residual rows (resid_init), and that path drains the queue (start_tile);
+    //  * the next tile's bias row (256 floats = one 1 KiB LDS-DMA piece) is fetched by wave 0 into LDS behind the ring (two slots,
+    //    alternating per tile: a wave may still be reading this tile's row) three iterations before the tile ends: the loop's own
+    //    counted waits + barriers cover it (two iterations later at the latest), and no register holds it across the epilogue.
+    //    K < 3 half-tiles: the draining path instead.
+    constexpr int BIAS_LDS = NSTAGE * STAGE;
+    const bool seamless = !resid_init && nh >= NSTAGE - 1;
     for (int r = 0; r < my_tiles; ++r) {
         // Fragment addresses: rows 16 apart share the swizzle (pp_f looks at bits 2..3 of the row), so the FM A fragments / 4 B
         // fragments of a wave are 1 KiB apart: one lane-dependent offset each + immediates.  The reads are inline asm (see
@@ -337,13 +379,21 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
             asm volatile("" ::: "memory");
         }
         PP_PHASE(3 + 4 * r)
-        auto half_tile = [&](auto CROSS_C) {
+        const int tile_next = r + 1 < my_tiles ? tile_of(r + 1) : tile;
+        const int m0_next = (tile_next / tiles_n) * BM, n0_next = (tile_next % tiles_n) * BN;
+        const bool fetch_bias = BIAS_IN_ACC && seamless && p.bias != nullptr && uwave == 0 && r + 1 < my_tiles;  // wave-uniform
+        for (int h = 0; h < nh; ++h, ++g) {
             const uint32_t soff = (uint32_t)(g & (NSTAGE - 1)) * STAGE;
+            if (fetch_bias && h == nh - (NSTAGE - 1)) {  // three iterations before the tile ends: covered by the loop's own waits
+                const int n = min(n0_next + (int)(threadIdx.x & 63) * 4, p.N - 4);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + n),
+                                                 (__attribute__((address_space(3))) void*)(smem + BIAS_LDS + ((r + 1) & 1) * 1024), 16, 0, 0);
+            }
             // ---------------- R(g): FN + FM fragment reads + the LDS-DMA pieces of half-tile g+3
             const uint32_t ab = lane_b + soff, aa = lane_a + soff;
             gd_static_for<0, FN>([&](auto I) { gt_ds_read128<decltype(I)::value * 1024>(fb[decltype(I)::value], ab); });
             gd_static_for<0, FM>([&](auto J) { gt_ds_read128<decltype(J)::value * 1024>(fa[decltype(J)::value], aa); });
-            pf_issue(CROSS_C, (g + NSTAGE - 1) & (NSTAGE - 1));
+            pf_issue((g + NSTAGE - 1) & (NSTAGE - 1));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int i = 0; i < FN; ++i) asm volatile("" : "+v"(fb[i]));
@@ -362,14 +412,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            pf_advance();  // tap / tile switch of the prefetch stream, if the next fetch needs one (fragment registers are dead here)
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-                };
-        // While h + 3 < nh the fetched half-tile belongs to this tile: the steady loop carries no tile-switch code (inlined into
-        // it, the address set-up of the next tile cost registers -- scratch traffic, whose waits drain the LDS-DMA queue).
-        int h = 0;
-        for (; h + NSTAGE - 1 < nh; ++h, ++g) half_tile(std::false_type{});
-        for (; h < nh; ++h, ++g) half_tile(std::true_type{});
+        }
         if (ugroup == 0) {  // re-join the groups
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -381,10 +428,59 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         }
         PP_PHASE(5 + 4 * r)
         if (r + 1 < my_tiles) {
-            tile = tile_of(r + 1);
-            m0 = (tile / tiles_n) * BM;
-            n0 = (tile % tiles_n) * BN;
-            start_tile(std::false_type{}, tile, m0 + wm * WM, n0 + wn * WN);
+            tile = tile_next;
+            m0 = m0_next;
+            n0 = n0_next;
+            if (!seamless) {
+                start_tile(std::false_type{}, tile, m0 + wm * WM, n0 + wn * WN);  // rows requested now, queue drained
+            } else if constexpr (BIAS_IN_ACC) {  // accumulators = the bias row in LDS (landed and fenced: see above)
+                const int fg_b = (threadIdx.x >> 4) & 3;
+                float b8[2][8];
+                if (p.bias != nullptr) {
+                    gt_u32x4 bl[2][2];
+                    const uint32_t ba = gt_lds_addr(smem) + BIAS_LDS + ((r + 1) & 1) * 1024 + (wn * WN + fg_b * 8) * 4;
+                    gt_ds_read128<0>(bl[0][0], ba);
+                    gt_ds_read128<16>(bl[0][1], ba);
+                    gt_ds_read128<128>(bl[1][0], ba);
+                    gt_ds_read128<144>(bl[1][1], ba);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        asm volatile("" : "+v"(bl[t][0]));
+                        asm volatile("" : "+v"(bl[t][1]));
+                        const bool ok = (n0 + wn * WN + t * 32 + fg_b * 8) < p.N;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            b8[t][e] = ok ? __uint_as_float(bl[t][0][e]) : 0.f;
+                            b8[t][4 + e] = ok ? __uint_as_float(bl[t][1][e]) : 0.f;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) b8[t][e] = 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        acc[2 * t][j] = (gt_f32x4){b8[t][0], b8[t][1], b8[t][2], b8[t][3]};
+                        acc[2 * t + 1][j] = (gt_f32x4){b8[t][4], b8[t][5], b8[t][6], b8[t][7]};
+                    }
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) asm volatile("" : "+v"(acc[i][j]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) {
+                        acc[i][j] = (gt_f32x4){0.f, 0.f, 0.f, 0.f};
+                        asm volatile("" : "+v"(acc[i][j]));
+                    }
+            }
         }
         PP_PHASE(6 + 4 * r)
     }
@@ -407,7 +503,7 @@ static int pp_num_cus() {
 
 template <typename T, int BM, bool TAPS, bool SUMS>
 static int pp_launch_one(const theia_gemm_args_t* a, hipStream_t stream) {
-    constexpr int lds = 4 * (BM + 256) * 64;
+    constexpr int lds = 4 * (BM + 256) * 64 + 2048;  // operand ring + two bias rows (this tile's, the next tile's)
     auto kern = gemm_nt_pp_kernel<T, BM, TAPS, SUMS>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -15,13 +15,27 @@ python - "$OUT/summary.txt" <<'PY'
 import json, re, sys
 txt = open(sys.argv[1]).read()
 out = {}
+agg = {}  # the persistent ping-pong kernel runs as several instantiations (tile height, tap gather, statistics): per-launch mean over all
 for block in re.split(r"\n(?=\S)", txt):
     lines = block.strip().split("\n")
-    vals = {m.group(1): float(m.group(2)) for m in (re.match(r"\s+(\w+)\s+([\d.]+)", l) for l in lines[1:]) if m}
+    vals, cnts = {}, {}
+    for l in lines[1:]:
+        m = re.match(r"\s+(\w+)\s+([\d.]+)\s+\(x(\d+)\)", l)
+        if m:
+            vals[m.group(1)], cnts[m.group(1)] = float(m.group(2)), int(m.group(3))
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         # guide (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts wide streaming reads at half their bytes on gfx950 -> x2; KB units
-        out[lines[0].strip()] = {"fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
-                                 "hbm_bytes_per_launch": round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)}
+        name = lines[0].strip()
+        out[name] = {"fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
+                     "hbm_bytes_per_launch": round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)}
+        m = re.match(r"(gemm_nt_pp_kernel<(bf16|float|fp8_t))", name)
+        if m:
+            a = agg.setdefault(m.group(1) + ", *> (all instantiations)", {"f": 0.0, "fn": 0, "w": 0.0, "wn": 0})
+            a["f"] += vals["FETCH_SIZE"] * cnts["FETCH_SIZE"]; a["fn"] += cnts["FETCH_SIZE"]
+            a["w"] += vals["WRITE_SIZE"] * cnts["WRITE_SIZE"]; a["wn"] += cnts["WRITE_SIZE"]
+for name, a in agg.items():
+    f, w = a["f"] / a["fn"], a["w"] / a["wn"]
+    out[name] = {"fetch_size_kb": round(f, 1), "write_size_kb": round(w, 1), "hbm_bytes_per_launch": round((2.0 * f + w) * 1024)}
 # hash of the NT kernel sources the counters were taken from: bench.py only reports `roofline.traffic` from a summary whose
 # hash matches the sources it runs (otherwise the number would silently go stale)
 import hashlib, os
