@@ -544,6 +544,43 @@ def test_attention_fwd_bwd(dt, hh):
     assert relerr(dqkv.float().view(b, n, 3 * D), r.grad) < (1e-4 if dt == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("sharp", [1.0, 3.0])
+def test_attention_bwd_per_tensor_bound_at_batch_8(sharp):
+    """The per-kernel bound behind the model-level bf16 gradient gates: the attention kernels alone, bf16, b = 8 x 12 heads x 197
+    tokens, with the logits as they come (sharp = 1) and three times sharper (a near-one-hot softmax, P stored as bf16 for the PV /
+    dV products), against an f64 evaluation of the same bf16 inputs.  Per tensor (dQ, dK, dV separately -- a max-norm over the whole
+    dQKV matrix is blind to the small ones): cosine > 0.99999, norm-relative error < 5e-3 (measured: 0.999996-0.999997, 2.3e-3-2.7e-3).  The model-level cosines of 0.991-0.994
+    (q_proj of the upper layers, the head LayerNorm affines) are NOT this kernel: they are the bf16 noise floor of a 12-layer
+    network on near-zero gradients (test_model_gpu.py::test_bf16_bench_dispatch_agrees_with_the_2stage_kernels)."""
+    from theia_amd import ops
+    dev = _dev()
+    dt = torch.bfloat16
+    b, n, hh = 8, 197, 12
+    D = hh * 64
+    qkv = h((b, n, 3 * D), 161, 1.5)
+    qkv[..., :2 * D] *= math.sqrt(sharp)  # q.k scales by `sharp`
+    r = rnd(qkv, dt).double().requires_grad_(True)
+    q, k, v = r.split(D, dim=-1)
+    q = q.view(b, n, hh, 64).transpose(1, 2)
+    k = k.view(b, n, hh, 64).transpose(1, 2)
+    v = v.view(b, n, hh, 64).transpose(1, 2)
+    p = torch.softmax((q @ k.transpose(-1, -2)) / 8.0, dim=-1)
+    ref = (p @ v).transpose(1, 2).reshape(b, n, D)
+    do = rnd(h((b, n, D), 162, 1.0), dt)
+    (ref * do.double()).sum().backward()
+    qd = qkv.to(dev, dt).view(b * n, 3 * D)
+    o, lse = ops.attention_fwd(qd, b, n, hh)
+    a, bb_ = o.double().cpu().reshape(-1), ref.detach().reshape(-1)
+    assert float((a - bb_).norm() / bb_.norm()) < 1e-2
+    dqkv = ops.attention_bwd(qd, o, do.to(dev, dt).view(b * n, D), lse, b, n, hh).double().cpu().view(b, n, 3 * D)
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        a, bb_ = dqkv[..., sl].reshape(-1), r.grad[..., sl].reshape(-1)
+        cos = float((a @ bb_) / (a.norm() * bb_.norm()))
+        err = float((a - bb_).norm() / bb_.norm())
+        print(f"[attention bwd b=8 sharp={sharp}] {name}: cosine {cos:.6f}, |a-b|/|b| {err:.4f}, max softmax weight {float(p.max()):.3f}")
+        assert cos > 0.99999 and err < 5e-3, (name, cos, err)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_distill_loss_against_oracle_and_golden(dt, golden_dir):
     from theia_amd import ops
