@@ -588,6 +588,9 @@ def main(argv=None):
             "settle_steps": settle_steps,
             "host_enqueue_ms_per_step": round(host_dt * 1e3, 3),
             "rccl_ranks": rccl_ranks,
+            "dp": None if world == 1 else {"exchange": ddp.reducer.exchange, "comm_dtype": ddp.reducer.comm_dtype,
+                                           "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
+                                           "cus_left_to_rccl_during_backward": ddp._reserve},
             "selfcheck": checks if checks else "skipped (--no-selfcheck): unchecked run",
             "model_flops_utilization": round(value / world * FLOPS_PER_IMAGE[(args.backbone, args.teachers)] / MFMA_BF16_PEAK, 4)
             if FLOPS_PER_IMAGE.get((args.backbone, args.teachers)) else None,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define THEIA_ABI_VERSION 4
+#define THEIA_ABI_VERSION 5
 
 enum { THEIA_OK = 0, THEIA_ERR_INVALID = -1, THEIA_ERR_LAUNCH = -2, THEIA_ERR_UNSUPPORTED = -3 };
 enum { THEIA_F32 = 0, THEIA_BF16 = 1,
@@ -38,6 +38,15 @@ int theia_abi_version(void);
 const char* theia_last_error(void);
 /* element size in bytes of a THEIA_* dtype */
 int theia_dtype_size(int dtype);
+/* Compute-unit budget of the GEMM planners (host-side state, read when a launch is enqueued).  The persistent NT kernel runs
+ * min(tiles, budget) workgroups and the weight-gradient planner (theia_wgrad_splits) fills `budget` CUs per launch; both kernels
+ * hold a whole CU per workgroup (130-150 KB of LDS, all of its registers), so a concurrent kernel that keeps k CUs -- RCCL runs one
+ * workgroup per channel for the length of a collective -- would push k workgroups of a 256-workgroup launch into a second round and
+ * double that launch's duration.  n = 0: every CU of the device (default); 0 < n: use n CUs (clamped to the device).  Replaces
+ * nothing in the reference (DDP + cuBLAS leave this to the hardware scheduler): train_rvfm.py:125,258 is where the overlap arises.
+ * Environment: THEIA_COMPUTE_CUS (initial value). */
+int theia_set_compute_cus(int n);
+int theia_get_compute_cus(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Row map: how GEMM row m of the (implicitly gathered) activation operand and of the output is found.
@@ -165,7 +174,7 @@ typedef struct theia_wgrad_args {
 
 int theia_gemm_wgrad(const theia_wgrad_args_t* args, int dtype, void* stream);
 int theia_wgrad_fuses_bias(const theia_wgrad_args_t* args, int dtype);
-/* recommended number of M-splits for (M, N, kslots*in_c) so that the launch fills 256 CUs */
+/* recommended number of M-splits for (M, N, kslots*in_c) so that the launch fills the CU budget (theia_get_compute_cus) */
 int theia_wgrad_splits(int M, int N, int Ktot);
 
 /* out[n*sn + slot*ss + ci*sc] (+)= sum_s slab[s][n][slot*C + ci]   (f32; permutes into the PyTorch layout) */

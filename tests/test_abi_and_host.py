@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/theia_hip.h but not exported"
     assert sorted(N.EXPORTED_SYMBOLS) == declared, "ctypes signature table and header disagree"
-    assert lib.theia_abi_version() == N.ABI_VERSION == 4
+    assert lib.theia_abi_version() == N.ABI_VERSION == 5
     assert lib.theia_dtype_size(N.F32) == 4 and lib.theia_dtype_size(N.BF16) == 2 and lib.theia_dtype_size(7) == -1
 
 
@@ -81,6 +81,37 @@ def test_host_side_planning_functions():
     w.map.in_c = 64
     assert lib.theia_wgrad_fuses_bias(w, N.BF16) == 0
     assert lib.theia_gemm_nt_tile(25216, 768, N.BF16) == 256256 and lib.theia_gemm_nt_tile(100, 64, N.BF16) in (128064, 128128)
+
+
+def test_compute_cu_budget_steers_the_planners():
+    """theia_set_compute_cus (host state, no GPU): the weight-gradient planner fills the budget, not the device; the tile-height choice
+    of the persistent NT kernel follows it; 0 restores the whole device (256 CUs when no device is visible)."""
+    from theia_amd import _native as N, ops
+    lib = N.lib()
+    try:
+        ops.set_compute_cus(0)
+        full = ops.get_compute_cus()
+        assert full == ops.device_cus() and full >= 64
+        if full != 256:
+            pytest.skip("planner expectations below are written for 256 CUs")
+        b, C = 128, 768
+        assert ops.wgrad_splits(b * 197, C, 4 * C) == 7 and ops.wgrad_splits(b * 256, C, 9 * C) == 3 and ops.wgrad_splits(b * 197, C, C) == 28
+        ops.set_compute_cus(240)
+        assert ops.get_compute_cus() == 240
+        # 36 / 81 / 9 tiles: one round of 240 CUs
+        assert ops.wgrad_splits(b * 197, C, 4 * C) == 6 and ops.wgrad_splits(b * 256, C, 9 * C) == 2 and ops.wgrad_splits(b * 197, C, C) == 26
+        g = N.GemmArgs()
+        g.M, g.N, g.K, g.act = b * 197, C, C, N.ACT_NONE
+        g.map = ops.rm_plain(C, C, C)
+        assert lib.theia_gemm_nt_plan(g, N.BF16) == 320256          # 237 tiles of 320 rows: still one round of 240
+        ops.set_compute_cus(200)
+        assert lib.theia_gemm_nt_plan(g, N.BF16) == 256256          # 2 rounds either way: 2 x 256 < 2 x 320
+        ops.set_compute_cus(100000)
+        assert ops.get_compute_cus() == full                       # clamped to the device
+        with pytest.raises(RuntimeError):
+            ops.set_compute_cus(-1)
+    finally:
+        ops.set_compute_cus(0)
 
 
 def test_every_bench_size_gemm_dispatches_the_pingpong_tile():

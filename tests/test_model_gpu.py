@@ -262,6 +262,49 @@ def test_bf16_bench_dispatch_agrees_with_the_2stage_kernels():
     assert cos > 0.99 and nr < 1.5e-2, (cos, nr, who)
 
 
+def test_cu_reservation_during_backward_changes_the_schedule_not_the_result(monkeypatch):
+    """What TheiaDataParallel does at N > 1 (theia_amd/parallel.py), exercised on one GPU: from the first completed gradient bucket
+    to the end of the backward pass the GEMM planners leave 16 CUs to RCCL (persistent NT grid 240, weight-gradient splits for 240
+    CUs).  The NT kernels compute every output element in the same order whatever the grid, so losses and data gradients are
+    bit-identical; the weight gradients are summed over a different number of f32 slabs -- f32 rounding, nothing more."""
+    from theia_amd import ops
+    from theia_amd.parallel import TheiaDataParallel
+    bb, teachers, B = "facebook/deit-base-patch16-224", O.TEACHER_SETS["cddsv"], 64
+    model, _ = build(bb, teachers, "bf16")
+    images = O.synth_images(B, 0)
+    targets = {t: v.to("cuda:0") for t, v in O.synth_targets(B, teachers, 1).items()}
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        losses = model.get_loss(model(images), targets)
+        (0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]).backward()
+        return losses
+
+    la = step()
+    ga = {k: p.grad.clone() for k, p in model.named_parameters()}
+    ddp = TheiaDataParallel(model, broadcast=False)  # world size 1: no collective, the reducer is a no-op
+    ddp._reserve = 16
+    model.engine.bucket_ready_hook = ddp._on_bucket
+    calls = []
+    real = ops.set_compute_cus
+    monkeypatch.setattr(ops, "set_compute_cus", lambda n: (calls.append(n), real(n))[1])
+    try:
+        lb = step()
+    finally:
+        model.engine.bucket_ready_hook = None
+        real(0)
+    full = ops.device_cus()
+    assert calls == [full - 16, 0] and ops.get_compute_cus() == full, calls
+    for k in ("mse_loss", "cos_loss", "l1_loss"):
+        assert float(la[k]) == float(lb[k])
+    worst = 0.0
+    for k, p in model.named_parameters():
+        a, b = ga[k].double(), p.grad.double()
+        worst = max(worst, float((a - b).norm() / a.norm().clamp_min(1e-30)))
+    print(f"[base bf16 B=64, 16 CUs reserved during backward] worst |dW - dW'| / |dW| = {worst:.2e}")
+    assert worst < 1e-5, worst
+
+
 def test_input_layouts_and_reduce_modes(golden_dir):
     """G6/G7: BHWC == BCHW == list-of-PIL inputs; handle_feature_output modes (models/utils.py:8-43)."""
     from PIL import Image

@@ -133,14 +133,26 @@ def test_reducer_averages_several_buckets_async(exchange, comm_dtype):
 
 
 def test_rccl_channel_cap_knob(monkeypatch):
-    from theia_amd.parallel import configure_rccl_env
+    from theia_amd.parallel import DEFAULT_RCCL_CHANNELS, configure_rccl_env, rccl_channels, reserved_cus
+    for v in ("NCCL_MAX_NCHANNELS", "THEIA_RCCL_MAX_NCHANNELS", "THEIA_DP_RESERVED_CUS"):
+        monkeypatch.delenv(v, raising=False)
+    configure_rccl_env()  # default: a cap, and as many CUs left to RCCL while buckets are exchanged
+    assert os.environ["NCCL_MAX_NCHANNELS"] == str(DEFAULT_RCCL_CHANNELS) and reserved_cus() == DEFAULT_RCCL_CHANNELS
     monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
-    monkeypatch.delenv("THEIA_RCCL_MAX_NCHANNELS", raising=False)
-    configure_rccl_env()
-    assert "NCCL_MAX_NCHANNELS" not in os.environ
     monkeypatch.setenv("THEIA_RCCL_MAX_NCHANNELS", "8")
     configure_rccl_env()
-    assert os.environ["NCCL_MAX_NCHANNELS"] == "8"
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "8" and rccl_channels() == 8 and reserved_cus() == 8
+    monkeypatch.setenv("THEIA_DP_RESERVED_CUS", "24")
+    assert reserved_cus() == 24
+    monkeypatch.delenv("THEIA_DP_RESERVED_CUS", raising=False)
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    monkeypatch.setenv("THEIA_RCCL_MAX_NCHANNELS", "0")  # RCCL's own defaults, nothing reserved
+    configure_rccl_env()
+    assert "NCCL_MAX_NCHANNELS" not in os.environ and reserved_cus() == 0
+    monkeypatch.delenv("THEIA_RCCL_MAX_NCHANNELS", raising=False)
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "12")       # a cap the user exported is respected and reserved for
+    configure_rccl_env()
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "12" and reserved_cus() == 12
     monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
 
 

@@ -121,3 +121,4 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 }
 
 static inline int cdiv_i(long a, long b) { return (int)((a + b - 1) / b); }
+int theia_compute_cus();  // CU budget of the GEMM planners (misc.hip: theia_set_compute_cus)

@@ -603,9 +603,9 @@ static bool wgrad_use_pp() {
 
 extern "C" int theia_wgrad_splits(int M, int N, int Ktot) {
     if (wgrad_use_pp() && Ktot % 256 == 0 && N >= 128) {
-        // ping-pong kernel: 256x256 output tiles, one workgroup per CU -> fill one round of 256 CUs as exactly as possible
+        // ping-pong kernel: 256x256 output tiles, one workgroup per CU -> fill one round of the CU budget as exactly as possible
         const int tiles = cdiv_i(N, 256) * (Ktot / 256);
-        int s = 256 / (tiles > 0 ? tiles : 1);
+        int s = theia_compute_cus() / (tiles > 0 ? tiles : 1);
         const int smax = cdiv_i(M, 32) / 8;
         if (s > smax) s = smax;
         if (s > 64) s = 64;

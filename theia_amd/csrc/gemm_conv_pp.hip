@@ -294,13 +294,12 @@ int theia_gemm_conv_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t
     // launch of 128-column tiles -- (tiles_n - 1) * images full tiles + 2 * images half tiles.  A half tile costs ~0.6 of a full one
     // (its R segments carry the same image-fragment reads for half the MFMAs), so this pays when it removes a whole round:
     // 128 images x 768 columns: 2 rounds -> 1 + 0.6.  THEIA_CONV_SPLIT=0: A/B switch.
-    static int split_ok = -1, cus = 0;
+    static int split_ok = -1;
     if (split_ok < 0) {
         const char* e = getenv("THEIA_CONV_SPLIT");
         split_ok = (e != nullptr && strcmp(e, "0") == 0) ? 0 : 1;
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
+    const int cus = theia_compute_cus();
     const int images = a->M / 256, tn = cdiv_i(a->N, 256);
     const long full = (long)images * tn;
     const double cost_plain = (double)cdiv_i(full, cus);

@@ -490,15 +490,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
 // ---------------------------------------------------------------------------------------------------------------- launch
 int g_pp_grid_cap = 0;  // > 0: cap on the persistent grid (tools/pp_bench.hip: forces several tiles per workgroup on small problems)
 static int pp_num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    static int forced = -1;
+    if (forced < 0) {
         const char* e = getenv("THEIA_PP_GRID");  // timing experiments: cap (or, with a huge value, lift) the persistent grid
-        if (e != nullptr && atoi(e) > 0) v = atoi(e);
-        n = v;
+        forced = e != nullptr && atoi(e) > 0 ? atoi(e) : 0;
     }
-    return g_pp_grid_cap > 0 ? g_pp_grid_cap : n;
+    return g_pp_grid_cap > 0 ? g_pp_grid_cap : forced > 0 ? forced : theia_compute_cus();
 }
 
 template <typename T, int BM, bool TAPS, bool SUMS>

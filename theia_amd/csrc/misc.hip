@@ -18,6 +18,34 @@ extern "C" const char* theia_last_error(void) { return g_err; }
 extern "C" int theia_abi_version(void) { return THEIA_ABI_VERSION; }
 extern "C" int theia_dtype_size(int dtype) { return dtype == THEIA_F32 ? 4 : dtype == THEIA_BF16 ? 2 : -1; }
 
+// ------------------------------------------------------------------------------------------------
+// CU budget of the GEMM planners (see theia_hip.h)
+// ------------------------------------------------------------------------------------------------
+static int g_compute_cus = -1;  // -1: not initialised; 0: whole device
+static int device_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+int theia_compute_cus() {
+    if (g_compute_cus < 0) {
+        const char* e = getenv("THEIA_COMPUTE_CUS");
+        g_compute_cus = e != nullptr && atoi(e) > 0 ? atoi(e) : 0;
+    }
+    const int dev = device_cus();
+    return g_compute_cus > 0 && g_compute_cus < dev ? g_compute_cus : dev;
+}
+extern "C" int theia_set_compute_cus(int n) {
+    THEIA_CHECK_ARG(n >= 0, "theia_set_compute_cus: n=%d", n);
+    g_compute_cus = n;
+    return THEIA_OK;
+}
+extern "C" int theia_get_compute_cus(void) { return theia_compute_cus(); }
+
 #define DISPATCH_T(dtype, CALL_BF16, CALL_F32, who)                 \
     if ((dtype) == THEIA_BF16) {                                    \
         CALL_BF16;                                                  \

@@ -240,6 +240,31 @@ def wgrad_splits(M: int, Nn: int, Ktot: int) -> int:
     return N.lib().theia_wgrad_splits(M, Nn, Ktot)
 
 
+_DEVICE_CUS = 0
+
+
+def device_cus() -> int:
+    """CUs of the device (the GEMM planners' budget when nothing is reserved)"""
+    global _DEVICE_CUS
+    if _DEVICE_CUS == 0:
+        cur = get_compute_cus()
+        set_compute_cus(0)
+        _DEVICE_CUS = get_compute_cus()
+        if cur != _DEVICE_CUS:
+            set_compute_cus(cur)
+    return _DEVICE_CUS
+
+
+def set_compute_cus(n: int) -> None:
+    """CU budget of the GEMM planners (persistent NT grid, weight-gradient splits); 0 = the whole device.  Host-side state read when
+    a launch is enqueued -- see theia_hip.h and parallel.TheiaDataParallel (CUs left to RCCL while gradients are exchanged)."""
+    N.check(N.lib().theia_set_compute_cus(int(n)), "theia_set_compute_cus")
+
+
+def get_compute_cus() -> int:
+    return N.lib().theia_get_compute_cus()
+
+
 def wgrad_reduce(slabs: torch.Tensor, splits: int, Nn: int, kslots: int, C: int, out: torch.Tensor, sn: int, ss: int, sc: int,
                  accumulate: bool) -> None:
     N.check(N.lib().theia_wgrad_reduce(slabs.data_ptr(), splits, Nn, kslots, C, out.data_ptr(), sn, ss, sc, int(accumulate),

@@ -19,16 +19,38 @@ import torch
 import torch.distributed as dist
 
 
+DEFAULT_RCCL_CHANNELS = 16
+
+
+def rccl_channels() -> int:
+    """Channels (= workgroups, = CUs held for the length of a collective) RCCL may use: ``THEIA_RCCL_MAX_NCHANNELS`` (0 = leave RCCL's
+    own default, no CU reservation), else a ``NCCL_MAX_NCHANNELS`` the user exported, else ``DEFAULT_RCCL_CHANNELS``."""
+    n = os.environ.get("THEIA_RCCL_MAX_NCHANNELS")
+    if n is not None and n != "":
+        return max(0, int(n))
+    n = os.environ.get("NCCL_MAX_NCHANNELS")
+    return int(n) if n else DEFAULT_RCCL_CHANNELS
+
+
 def configure_rccl_env() -> None:
     """Environment RCCL reads when the communicator is created -- call before ``init_process_group``.
 
-    ``THEIA_RCCL_MAX_NCHANNELS=<n>`` caps the number of channels (= workgroups) RCCL runs a collective with (``NCCL_MAX_NCHANNELS``):
-    the bucket all-reduces overlap the data-gradient GEMMs, whose persistent kernel wants every CU (one 147 KB-LDS workgroup each);
-    an all-reduce that takes fewer CUs for longer can be the better trade on xGMI, where a ring is bound per link (~153 GB/s), not
-    by how many CUs copy."""
-    n = os.environ.get("THEIA_RCCL_MAX_NCHANNELS")
-    if n:
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(int(n)))
+    Caps the number of channels RCCL runs a collective with (``NCCL_MAX_NCHANNELS`` = ``rccl_channels()``, 16 unless told otherwise).
+    The bucket all-reduces overlap the backward GEMMs; the persistent NT kernel and the weight-gradient kernel run one workgroup per
+    CU with all of its registers and 130-150 KB of its LDS, so an RCCL workgroup cannot share a CU with them: every CU a collective
+    holds pushes one workgroup of a 256-workgroup launch into a second round.  The two sides are therefore given disjoint CU sets:
+    RCCL at most ``rccl_channels()`` CUs, the GEMM planners the rest while a gradient exchange is in flight (``TheiaDataParallel``
+    -> ``theia_set_compute_cus``).  On xGMI a ring is bound per link (~153 GB/s), not by how many CUs copy, so few channels for
+    longer is the cheap side of that trade.  ``THEIA_RCCL_MAX_NCHANNELS=0``: RCCL's defaults, nothing reserved."""
+    n = rccl_channels()
+    if n > 0:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
+
+
+def reserved_cus() -> int:
+    """CUs left to RCCL while gradient buckets are being exchanged: ``THEIA_DP_RESERVED_CUS`` or ``rccl_channels()``."""
+    n = os.environ.get("THEIA_DP_RESERVED_CUS")
+    return max(0, int(n)) if n else rccl_channels()
 
 
 class GradBucketReducer:
@@ -169,7 +191,10 @@ def broadcast_parameters(params, src: int = 0, process_group=None, bucket_bytes:
 
 
 class TheiaDataParallel(torch.nn.Module):
-    """``DDP``-shaped wrapper: exposes ``.module``, ``parameters()``, ``train()/eval()``, ``__call__``."""
+    """``DDP``-shaped wrapper: exposes ``.module``, ``parameters()``, ``train()/eval()``, ``__call__``.
+
+    While gradient buckets are being exchanged (from the first completed bucket of a backward pass to the end of that pass) the GEMM
+    planners are told to leave ``reserved_cus()`` CUs to RCCL (``theia_set_compute_cus``); forward passes use the whole device."""
 
     def __init__(self, module: torch.nn.Module, process_group=None, broadcast: bool = True):
         super().__init__()
@@ -178,18 +203,30 @@ class TheiaDataParallel(torch.nn.Module):
         if broadcast:
             broadcast_parameters(module.parameters(), 0, process_group)
         self._callback_queued = False
+        self._reserve = 0
         if self.reducer.world > 1:
             module.engine.bucket_ready_hook = self._on_bucket
+            first = next(iter(module.parameters()), None)
+            if first is not None and first.is_cuda and dist.get_backend(process_group) == "nccl":
+                self._reserve = reserved_cus()
+
+    def _set_cus(self, reserve: int) -> None:
+        from . import ops
+        ops.set_compute_cus(0 if reserve == 0 else max(64, ops.device_cus() - reserve))
 
     def _on_bucket(self, bucket, side_event=None) -> None:
         if not self._callback_queued:
             # runs once when the current backward pass has finished (same mechanism DDP uses)
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
             self._callback_queued = True
+            if self._reserve:
+                self._set_cus(self._reserve)  # launches enqueued from here on leave these CUs to the collectives
         self.reducer.bucket_ready(bucket.flat, side_event)
 
     def _finalize(self) -> None:
         self.reducer.finish()
+        if self._reserve:
+            self._set_cus(0)
         self._callback_queued = False
 
     def forward(self, *args, **kwargs):
