@@ -595,8 +595,6 @@ def main(argv=None):
             "model_flops_utilization": round(value / world * FLOPS_PER_IMAGE[(args.backbone, args.teachers)] / MFMA_BF16_PEAK, 4)
             if FLOPS_PER_IMAGE.get((args.backbone, args.teachers)) else None,
         }
-        if args.backbone != BACKBONE:
-            out["metric"] = f"images/sec train-step (fwd+bwd+allreduce) {args.backbone.split('/')[-1]} 5-teacher"
         if roofline is not None:
             out["roofline"] = roofline
         if student is not None:

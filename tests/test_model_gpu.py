@@ -202,8 +202,8 @@ def test_bf16_base_cddsv_on_the_pingpong_kernels_vs_oracle():
     """BASELINE config 3 in its stated mode: DeiT-base + 5 teachers (cddsv), bf16.  At B = 8 the library would pick 128-wide
     tiles, so every GEMM is forced onto the 256x256 ping-pong kernel the per-GPU-batch-128 bench runs on (ragged tiles in M:
     8*197 = 6.16 tiles; all row maps of the translator heads).  Checked against the CPU oracle's fp32 losses and gradients.
-    Tolerances (bf16 operands / activations, f32 accumulate): losses 2e-2 rel, per-tensor gradient cosine > 0.98 and
-    gradient-norm ratio within 5 %."""
+    Tolerances (bf16 operands / activations, f32 accumulate): losses 2e-2 rel, per-tensor gradient cosine > 0.99 and
+    gradient-norm ratio within 2.5 % for tensors of >= 4096 elements, norm-relative error < 0.2 for the smaller ones."""
     bb, teachers, B = "facebook/deit-base-patch16-224", O.TEACHER_SETS["cddsv"], 8
     model, params = build(bb, teachers, "bf16")
     images = O.synth_images(B, 0)
@@ -220,8 +220,8 @@ def test_bf16_base_cddsv_on_the_pingpong_kernels_vs_oracle():
     small, who_small = _grad_agreement.small
     print(f"[base bf16 pp] worst gradient cosine {cos:.5f} ({who}), worst norm-ratio error {nr:.4f}; "
           f"tensors < 4096 elements: worst |a-b|/|b| {small:.4f} ({who_small})")
-    assert cos > 0.98 and nr < 5e-2, (cos, nr, who)
-    assert small < 0.25, (small, who_small)
+    assert cos > 0.99 and nr < 2.5e-2, (cos, nr, who)  # measured: 0.9933 / 0.0103 -- the bf16 noise floor of this network
+    assert small < 0.2, (small, who_small)           # measured: 0.112
 
 
 def test_bf16_bench_dispatch_agrees_with_the_2stage_kernels():
@@ -285,6 +285,7 @@ def test_cu_reservation_during_backward_changes_the_schedule_not_the_result(monk
     ddp = TheiaDataParallel(model, broadcast=False)  # world size 1: no collective, the reducer is a no-op
     ddp._reserve = 16
     model.engine.bucket_ready_hook = ddp._on_bucket
+    full = ops.device_cus()  # (first use probes the device through set_compute_cus: before the spy goes in)
     calls = []
     real = ops.set_compute_cus
     monkeypatch.setattr(ops, "set_compute_cus", lambda n: (calls.append(n), real(n))[1])
@@ -293,7 +294,6 @@ def test_cu_reservation_during_backward_changes_the_schedule_not_the_result(monk
     finally:
         model.engine.bucket_ready_hook = None
         real(0)
-    full = ops.device_cus()
     assert calls == [full - 16, 0] and ops.get_compute_cus() == full, calls
     for k in ("mse_loss", "cos_loss", "l1_loss"):
         assert float(la[k]) == float(lb[k])
