@@ -245,6 +245,40 @@ def test_conv_family_fwd_dgrad_wgrad(dt, kind, C, tile):
     assert relerr(gb2 - 0.5, gyr.double().sum((0, 1, 2))) < 1e-5
 
 
+@pytest.mark.parametrize("kind", ["conv_p1", "convT_s1"])
+@pytest.mark.parametrize("b", [29, 37])
+def test_conv_wgrad_periodic_rows_with_uneven_splits(b, kind):
+    """The weight-gradient kernel's periodic row mode (16x16 output maps: a step of 32 rows is two image rows, so there is no x wrap,
+    the y wrap falls on the step that re-enters an image, and whether a tap's input pixel exists repeats every 8 steps; each staged row
+    tests one bit of a mask built once).  conv_p1: dense 16x16 input; convT_s1: 14x14 input under a 16x16 output (non-zero image-wrap
+    constant on the input side).  b = 29 / 37 images of 256 channels give 28 splits of 9 / 11 steps, so the splits start at every
+    phase of the period (the 3-image case of test_conv_family_fwd_dgrad_wgrad only ever starts at phase 0), and the last split is
+    ragged.  Against the oracle's shifted-matmul convolution, for the bf16 ping-pong kernel and -- same rounded inputs -- the exact-f32
+    2-stage kernel."""
+    from theia_amd import ops
+    dev = _dev()
+    C, dt = 256, torch.bfloat16
+    IH = 16 if kind == "conv_p1" else 14
+    x = h((b, IH, IH, C), 31, 1.0)
+    W = h((C, C, 3, 3), 32, 1.0 / math.sqrt(9 * C))
+    xr, Wr = rnd(x, dt), rnd(W, dt)
+    Wr.requires_grad_(True)
+    if kind == "conv_p1":
+        plan, ref = ops.plan_conv3x3(C, IH), O.conv3x3_p1(xr, Wr, torch.zeros(C))
+    else:
+        plan, ref = ops.plan_convT3x3(C, IH, 1, 0, 0), O.convT3x3(xr, Wr, torch.zeros(C), 1, 0, 0)
+    assert ref.shape == (b, 16, 16, C) and not plan.wgrad_swapped
+    gy = h((b, 16, 16, C), 34, 1.0)
+    (ref * rnd(gy, dt)).sum().backward()
+    M = b * 256
+    splits = ops.wgrad_splits(M, C, 9 * C)
+    assert splits == 28 and -(-(M // 32) // splits) % 8 != 0  # uneven: steps per split not a multiple of the period
+    for t in (dt, torch.float32):
+        gw = torch.zeros(C, C, 3, 3, dtype=torch.float32, device=dev)
+        ops.conv_wgrad(plan, rnd(gy, dt).to(dev, t).view(b, -1), xr.detach().to(dev, t).view(b, -1), b, C, gw, accumulate=False)
+        assert relerr(gw, Wr.grad) < (1e-4 if t == torch.float32 else 2e-3), t  # same bf16-rounded inputs, f32 accumulation in both
+
+
 @pytest.mark.parametrize("tile", TILES + [256009])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_pad_convT_on_strided_tokens(dt, tile):

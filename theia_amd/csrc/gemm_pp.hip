@@ -54,7 +54,7 @@ template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_
 
 // T: operand type.  BM: tile rows.  TAPS: multi-tap (3x3 gather) row maps; false = single-tap maps only.  SUMS: ln_sums epilogue.
 template <typename T, int BM, bool TAPS, bool SUMS>
-__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t p, const int ntiles) {
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t p, const int ntiles, const int panel) {
     constexpr int BN = 256, WAVES_N = 4;
     constexpr int NSTAGE = 4;
     constexpr int HKT = 64 / (int)sizeof(T);
@@ -85,7 +85,23 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
     const int rounds = (ntiles + grid - 1) / grid;
     const int cnt_last = ntiles - (rounds - 1) * grid;
     const int my_tiles = rounds - 1 + (bid < cnt_last ? 1 : 0);
-    auto tile_of = [&](int r) { return r * grid + gt_xcd_remap(bid, r + 1 < rounds ? grid : cnt_last); };
+    // Schedule position -> tile (row block * tiles_n + column block).  panel == 0: row-major -- a round's 32 consecutive positions of an
+    // XCD are ~32 / tiles_n row blocks x every column block: each activation row block enters one L2 once, and the XCD streams the
+    // whole weight matrix every round.  That is the right trade while the weights fit in the 4 MB L2 beside the activation stream; for
+    // N = 3072, K = 768 (4.7 MB) they do not, and the PMC summary showed 2.4x the algorithmic fetch for those launches (the weights
+    // re-fetched by every XCD in every round).  panel = G > 0: positions run down panels of G column blocks (row blocks fastest across a
+    // panel's G columns), so an XCD keeps G weight column blocks hot across rounds and re-reads each activation row block once per panel.
+    auto tile_of = [&](int r) {
+        const int t = r * grid + gt_xcd_remap(bid, r + 1 < rounds ? grid : cnt_last);
+        if (panel <= 0) return t;
+        const int tiles_m = ntiles / tiles_n;
+        const int per = panel * tiles_m, full = tiles_n / panel;
+        const int pi = min(t / per, full);                       // panel index; the last one may be narrower
+        const int cols = pi < full ? panel : tiles_n - full * panel;
+        const int rem = t - pi * per;
+        const int m = rem / cols, n = pi * panel + (rem - m * cols);
+        return m * tiles_n + n;
+    };
     const T* __restrict__ A = reinterpret_cast<const T*>(p.a);
     const T* __restrict__ W = reinterpret_cast<const T*>(p.w);
     const int R = mp.rows_h * mp.rows_w;
@@ -509,7 +525,23 @@ static int pp_launch_one(const theia_gemm_args_t* a, hipStream_t stream) {
     }
     const int tiles = cdiv_i(a->M, BM) * cdiv_i(a->N, 256);
     const int grid = tiles < pp_num_cus() ? tiles : pp_num_cus();
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, *a, tiles);
+    // column panels (see tile_of): only when the weight matrix does not fit an XCD's L2 beside the activation stream and there are enough
+    // column blocks to group; G column blocks of ~1.6 MB together.  THEIA_PP_PANEL=0: off (A/B), =G: forced width
+    static int panel_env = -2;
+    if (panel_env == -2) {
+        const char* e = getenv("THEIA_PP_PANEL");
+        panel_env = e == nullptr ? -1 : atoi(e);
+    }
+    const int tn = cdiv_i(a->N, 256);
+    const long wbytes = (long)a->N * a->K * (long)sizeof(T), colblock = 256L * a->K * (long)sizeof(T);
+    int panel = 0;
+    if (panel_env > 0) panel = panel_env < tn ? panel_env : 0;
+    else if (panel_env < 0 && tn >= 8 && wbytes > (3L << 20) && tiles > grid) {
+        panel = (int)((1600L << 10) / colblock);
+        if (panel < 1) panel = 1;
+        if (panel >= tn) panel = 0;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, *a, tiles, panel);
     THEIA_CHECK_LAUNCH("theia_gemm_nt(pp)");
     return THEIA_OK;
 }
@@ -530,7 +562,9 @@ int theia_gemm_nt_pp_bm(const theia_gemm_args_t* a, int dtype) {
     const int cus = pp_num_cus(), tn = cdiv_i(a->N, 256);
     const double c256 = (double)cdiv_i((long)cdiv_i(a->M, 256) * tn, cus) * 256.0;
     const double c320 = (double)cdiv_i((long)cdiv_i(a->M, 320) * tn, cus) * 320.0;
-    return c320 < c256 ? 320 : 256;
+    // ties go to 256 rows -- except for launches that store two tensors per tile (GELU output + saved pre-activation): fewer, taller
+    // tiles mean fewer chip-wide store bursts (fc1 forward, 4 rounds of 320 vs 5 of 256: 163 vs 182 us, r03_ab_tile_order_and_height.txt)
+    return c320 < c256 || (c320 == c256 && a->aux_out != nullptr) ? 320 : 256;
 }
 
 int theia_gemm_nt_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t stream) {

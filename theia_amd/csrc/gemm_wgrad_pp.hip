@@ -17,6 +17,7 @@
 typedef __attribute__((ext_vector_type(4))) short wp_s16x4;
 
 __device__ uint4 g_wp_zero_page[16];
+template <int N> __device__ __forceinline__ void wp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ uint4 wp_tr_frag(const char* __restrict__ part, int lb, int lane) {
     const int q = lane & 15, g = lane >> 4;
@@ -30,11 +31,24 @@ __device__ __forceinline__ uint4 wp_tr_frag(const char* __restrict__ part, int l
 }
 
 // FAST: constant-step row addressing (see below); the host picks the instantiation, so the hot loop carries one path only
-// SPLIT_ISSUE: where the LDS-DMA of half-step h+3 is issued (A/B switch THEIA_WGRAD_ISSUE=m: both rows in the M segment)
-template <bool FAST, bool SPLIT_ISSUE = true>
+// SPLIT_ISSUE: where the LDS-DMA of half-step h+NSTAGE-1 is issued (A/B switch THEIA_WGRAD_ISSUE=m: both rows in the M segment)
+// NSTAGE: ring depth, 4 (128 KB of LDS) or 5 (all 160 KB: one more half-step of prefetch distance; THEIA_WGRAD_STAGES)
+// MODE (of the FAST instantiation; THEIA_WGRAD_MODES=0: A/B switch, everything on mode 0):
+//   0  stepping: per row (y, x) state, one address constant per step + one per pixel wrap + one per image wrap (any map that qualifies
+//      for FAST)
+//   1  plain row-major matrices (one row per "image", one tap at (0, 0): the nn.Linear launches) -- a staged row is valid iff it lies
+//      inside the split and advances by one constant; no (y, x) state, no wrap selects
+//   2  periodic: images whose pixel count is a multiple of 32 with at most 32 steps per image and whose width divides 32 (16x16 maps: 8
+//      steps of two image rows).  A step then never wraps in x, wraps in y exactly when the step index inside the image returns to 0
+//      -- for every row of the workgroup at once, so the wrap constant is a scalar select -- and whether the tap's input pixel exists
+//      repeats with that period: each staged row carries a bit mask built once and the loop tests one bit of it
+// Measured (profiles/r03_ab_wgrad_row_modes.txt): the ~35 VALU instructions per staged row of mode 0 sit in the R / M segments of every
+// half-step; mode 1 took 19 % off the ViT weight-gradient launches.
+template <bool FAST, bool SPLIT_ISSUE = true, int NSTAGE = 4, int MODE = 0>
 __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_args_t p, const int plain_order) {
     constexpr bool wgrad_split_issue = SPLIT_ISSUE;
-    constexpr int NSTAGE = 4, MS = 32, ROWB = 512, PART = MS * ROWB, STAGE = 2 * PART;
+    constexpr int MS = 32, ROWB = 512, PART = MS * ROWB, STAGE = 2 * PART;
+    constexpr int AHEAD = NSTAGE - 1;  // half-steps in flight ahead of the one being multiplied; 4 LDS-DMA operations per thread each
     constexpr int FM = 8, FN = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,6 +121,20 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     const int rx_lo = dx >= 0 ? 0 : (-dx + mp.in_sx - 1) / mp.in_sx, rx_hi = dx >= mp.in_w ? 0 : (mp.in_w - dx + mp.in_sx - 1) / mp.in_sx;
     const unsigned ry_span = ry_hi > ry_lo ? (unsigned)(ry_hi - ry_lo) : 0u, rx_span = rx_hi > rx_lo ? (unsigned)(rx_hi - rx_lo) : 0u;
     uint64_t f_py[2], f_px[2];   // addresses of the row's dY / activation piece (valid or not)
+    uint32_t vmask[2] = {0u, 0u};  // MODE 2: bit k = the tap's input pixel exists for this row in step k of an image
+    const int period = R_img / MS;
+    int phase[2];                  // MODE 2: step inside the image of the row's NEXT issue (uniform)
+    phase[0] = phase[1] = MODE == 2 ? s_begin % period : 0;
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            for (int k = 0; k < period; ++k) {
+                const int rem = srow + 16 * i + MS * k;
+                const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
+                const bool ok = ((unsigned)(ry - ry_lo) < ry_span) & ((unsigned)(rx - rx_lo) < rx_span);
+                vmask[i] |= (ok ? 1u : 0u) << k;
+            }
+    }
     if constexpr (fast) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -122,7 +150,14 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     auto issue_row = [&](int i, char* slot) {
         const bool mok = st_m[i] < m_limit;
         uint64_t sy, sx;
-        if constexpr (fast) {
+        if constexpr (MODE == 1) {
+            sy = (mok & n_ok) ? f_py[i] : zp;
+            sx = mok ? f_px[i] : zp;
+        } else if constexpr (MODE == 2) {
+            const bool xok = mok & (((vmask[i] >> phase[i]) & 1u) != 0u);
+            sy = (mok & n_ok) ? f_py[i] : zp;
+            sx = xok ? f_px[i] : zp;
+        } else if constexpr (fast) {
             const bool xok = mok & ((unsigned)(st_ry[i] - ry_lo) < ry_span) & ((unsigned)(st_rx[i] - rx_lo) < rx_span);
             sy = (mok & n_ok) ? f_py[i] : zp;
             sx = xok ? f_px[i] : zp;
@@ -140,6 +175,18 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sy, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx, (__attribute__((address_space(3))) void*)(dst + PART), 16, 0, 0);
         st_m[i] += MS;
+        if constexpr (MODE == 1) {
+            f_py[i] += (uint64_t)(int64_t)by_step;
+            f_px[i] += (uint64_t)(int64_t)bx_step;
+            return;
+        }
+        if constexpr (MODE == 2) {  // phase is wave-uniform: the image wrap is a scalar select
+            const bool wrap = phase[i] + 1 == period;
+            f_py[i] += (uint64_t)(int64_t)(wrap ? by_step + by_wy : by_step);
+            f_px[i] += (uint64_t)(int64_t)(wrap ? bx_step + bx_wy : bx_step);
+            phase[i] = wrap ? 0 : phase[i] + 1;
+            return;
+        }
         if constexpr (fast) {  // constants per step; one more per wrap (never for whole_images: q32 = r32 = 0, R = 1 keeps rx = ry = 0)
             int rx = st_rx[i] + r32;
             const bool wx = rx >= mp.rows_w;
@@ -182,13 +229,13 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     for (int i = 0; i < FN; ++i) bacc[i] = (gt_f32x4){0.f, 0.f, 0.f, 0.f};
     const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
 
-    // prologue: half-steps 0..2 (rows past the split end read zeros)
+    // prologue: half-steps 0..AHEAD-1 (rows past the split end read zeros)
 #pragma unroll
-    for (int h = 0; h < NSTAGE - 1; ++h) {
+    for (int h = 0; h < AHEAD; ++h) {
         issue_row(0, smem + h * STAGE);
         issue_row(1, smem + h * STAGE);
     }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // half-step 0 landed
+    wp_wait_vm<(AHEAD - 1) * 4>();  // half-step 0 landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (ugroup == 1) {
@@ -197,10 +244,13 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     }
 
     uint4 fb[FN];
+    int cur = 0, nxt = AHEAD;  // ring slots of half-step h and of half-step h + AHEAD (NSTAGE need not be a power of two)
     for (int h = 0; h < nh; ++h) {
-        char* nslot = smem + ((h + NSTAGE - 1) & (NSTAGE - 1)) * STAGE;
-        const char* sy = smem + (h & (NSTAGE - 1)) * STAGE;  // dY part; activation part follows
+        char* nslot = smem + nxt * STAGE;
+        const char* sy = smem + cur * STAGE;  // dY part; activation part follows
         const char* sx = sy + PART;
+        cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+        nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
         {
             // ---------------- R(h): 12 transposed fragments (24 ds_read_b64_tr_b16)
             uint4 fa[FM];
@@ -208,18 +258,18 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
             for (int i = 0; i < FN; ++i) fb[i] = wp_tr_frag(sy, wn * 4 + i, lane);
 #pragma unroll
             for (int j = 0; j < FM; ++j) fa[j] = wp_tr_frag(sx, wm * 8 + j, lane);
-            // Row 0 of half-step h+3 is issued here, row 1 between the MFMAs below: an issue_row is 2 LDS-DMA instructions (~100
+            // Row 0 of half-step h+AHEAD is issued here, row 1 between the MFMAs below: an issue_row is 2 LDS-DMA instructions (~100
             // issue cycles each) + ~40 VALU.  With both in the M segment it was ~1200 cycles against ~600 for R -- the matrix pipe 40 %
             // busy (PMC) -- since the other group's R segment cannot run longer than this group's M; one in each balances them.
             if (wgrad_split_issue) issue_row(0, nslot);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // half-step h+1 landed; h+2 (4 operations) and, when issued above, row 0 of h+3 (2) may still be in flight
-            if (wgrad_split_issue) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // half-step h+1 landed; h+2 .. h+AHEAD-1 (4 operations each) and, when issued above, row 0 of h+AHEAD (2) may still be in flight
+            if (wgrad_split_issue) wp_wait_vm<(AHEAD - 2) * 4 + 2>();
+            else wp_wait_vm<(AHEAD - 2) * 4>();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            // ---------------- M(h): 32 MFMAs + both rows of half-step h+3
+            // ---------------- M(h): 32 MFMAs + row 1 (or both rows) of half-step h+AHEAD
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
@@ -281,13 +331,22 @@ bool theia_gemm_wgrad_pp_supported(const theia_wgrad_args_t* a) { return a->map.
 // bf16 only; requires in_c % 256 == 0.  Returns THEIA_ERR_UNSUPPORTED when the shape does not qualify.
 int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) {
     if (!theia_gemm_wgrad_pp_supported(a)) return THEIA_ERR_UNSUPPORTED;
-    constexpr int lds = 4 * 2 * 32 * 512;
+    constexpr int lds4 = 4 * 2 * 32 * 512, lds5 = 5 * 2 * 32 * 512;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true, true, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds5);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true, true, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true, true, 5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds5);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true, true, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
         attr_set = true;
+    }
+    static int stages = -1;  // THEIA_WGRAD_STAGES=4|5: ring depth of the stepping instantiation
+    if (stages < 0) {
+        const char* e = getenv("THEIA_WGRAD_STAGES");
+        stages = e != nullptr && atoi(e) == 5 ? 5 : 4;
     }
     const int tiles = cdiv_i(a->N, 256) * a->map.ntaps * (a->map.in_c / 256);
     static int allow_fast = -1;  // THEIA_WGRAD_STEP=general: A/B switch for the row-stepping fast path
@@ -313,9 +372,23 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
         const char* e = getenv("THEIA_WGRAD_XCD");
         plain_order = (e != nullptr && strcmp(e, "0") == 0) ? 1 : 0;
     }
-    if (fast && issue_in_m) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, false>), dim3(tiles * a->splits), dim3(512), lds, stream, *a, plain_order);
-    else if (fast) hipLaunchKernelGGL(gemm_wgrad_pp_kernel<true>, dim3(tiles * a->splits), dim3(512), lds, stream, *a, plain_order);
-    else hipLaunchKernelGGL(gemm_wgrad_pp_kernel<false>, dim3(tiles * a->splits), dim3(512), lds, stream, *a, plain_order);
+    static int allow_modes = -1;
+    if (allow_modes < 0) {
+        const char* e = getenv("THEIA_WGRAD_MODES");
+        allow_modes = (e != nullptr && strcmp(e, "0") == 0) ? 0 : 1;
+    }
+    const theia_rowmap_t& mp = a->map;
+    const bool modes = fast && allow_modes && !issue_in_m;
+    const bool plain = modes && R_img == 1 && mp.ntaps == 1 && mp.dy[0] == 0 && mp.dx[0] == 0 && mp.in_h >= 1 && mp.in_w >= 1;
+    // mode 2: no x wrap inside a step (the image width divides 32), whole steps per image, a period that fits the 32-bit mask
+    const bool periodic = modes && !plain && stages == 4 && R_img % 32 == 0 && R_img / 32 <= 32 && 32 % mp.rows_w == 0;
+    if (plain && stages == 5) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 5, 1>), dim3(tiles * a->splits), dim3(512), lds5, stream, *a, plain_order);
+    else if (plain) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 1>), dim3(tiles * a->splits), dim3(512), lds4, stream, *a, plain_order);
+    else if (periodic) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 2>), dim3(tiles * a->splits), dim3(512), lds4, stream, *a, plain_order);
+    else if (fast && issue_in_m) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, false>), dim3(tiles * a->splits), dim3(512), lds4, stream, *a, plain_order);
+    else if (fast && stages == 5) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 5>), dim3(tiles * a->splits), dim3(512), lds5, stream, *a, plain_order);
+    else if (fast) hipLaunchKernelGGL(gemm_wgrad_pp_kernel<true>, dim3(tiles * a->splits), dim3(512), lds4, stream, *a, plain_order);
+    else hipLaunchKernelGGL(gemm_wgrad_pp_kernel<false>, dim3(tiles * a->splits), dim3(512), lds4, stream, *a, plain_order);
     THEIA_CHECK_LAUNCH("theia_gemm_wgrad(pp)");
     if (a->bias_out != nullptr && a->defer_bias_reduce == 0) {
         hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv_i(a->N, 256)), dim3(256), 0, stream, a->bias_slabs, a->splits, a->N,

@@ -8,6 +8,10 @@
 #include <string>
 #include "../theia_amd/csrc/gemm_pp.hip"
 
+int theia_compute_cus() {  // (misc.hip in the library)
+    int v = 0;
+    return hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, 0) == hipSuccess && v > 0 ? v : 256;
+}
 void theia_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 
 static uint32_t rng_state = 12345u;
