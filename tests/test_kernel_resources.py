@@ -66,10 +66,10 @@ def test_gemm_and_attention_kernels_do_not_spill(tmp_path):
     with cf.ThreadPoolExecutor(max_workers=len(FILES)) as ex:
         rows = [r for rs in ex.map(lambda f: _resources(f, str(tmp_path)), FILES) for r in rs]
     assert len(rows) >= 30  # every instantiation of the five files
-    # The 320-row instantiations of the persistent ping-pong kernel (160 accumulator + 56 fragment registers) keep <= 128 bytes of
+    # The 320-row instantiations of the persistent ping-pong kernel (160 accumulator + 56 fragment registers) keep <= 144 bytes of
     # long-lived values (thread index, lane constants, the prefetch pointers around the epilogue) in scratch: stored / reloaded at tile
     # boundaries -- the main loops themselves are checked to be scratch-free above.  Everything else: no scratch at all.
-    spilled = [(f, n, s) for f, n, s, _v in rows if s != 0 and not ("Li320E" in n and s <= 128)]
+    spilled = [(f, n, s) for f, n, s, _v in rows if s != 0 and not ("Li320E" in n and s <= 144)]
     assert not spilled, spilled
     # the ping-pong kernels run 8 waves per CU on 512 registers per SIMD lane: 2 waves per SIMD need <= 256 each
     assert all(v <= 256 for _f, _n, _s, v in rows)

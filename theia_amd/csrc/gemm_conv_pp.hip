@@ -65,6 +65,10 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
     const T* __restrict__ W = reinterpret_cast<const T*>(p.w);
     const uint64_t zp = reinterpret_cast<uint64_t>(g_cv_zero_page);
 
+    if constexpr (SUMS) {  // the statistics table behind the ring and the epilogue's staging areas (see the end of the kernel)
+        constexpr int ring_bytes_ = NB * BTILE + 2 * ATILE, ep_bytes_ = 8 * 64 * (WN + 4) * 4;
+        if (tid < 2 * GT_SUMS_SLOTS) reinterpret_cast<unsigned long long*>(smem + (ring_bytes_ > ep_bytes_ ? ring_bytes_ : ep_bytes_))[tid] = 0ull;
+    }
     // zero pads of the two image buffers (4 x 2 KiB = 512 x 16 B): never touched by the LDS-DMA, read by fragments whose pixel
     // row is above / below the image and by the lanes whose pixel column is outside it
     {
@@ -229,7 +233,16 @@ __global__ __launch_bounds__(512) void gemm_conv_pp_kernel(const theia_gemm_args
 
     float* ep = reinterpret_cast<float*>(smem) + wave * (64 * (WN + 4));
     const bool prefetch = sizeof(T) == 2 && (p.resid != nullptr || p.act == THEIA_ACT_MUL_DGELU || p.act == THEIA_ACT_MUL_DRELU);
-    if constexpr (SUMS) gt_epilogue<T, WM, WN, true, false, 4, 0>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);  // see gemm_pp.hip
+    if constexpr (SUMS) {
+        // the tile is one image: the eight waves' (sum, sum of squares) meet in LDS and one wave adds them to global memory -- two
+        // device-scope atomics per tile instead of sixteen (they serialise per address at the memory side: gemm_epi_direct.h)
+        constexpr int ring_bytes = NB * BTILE + 2 * ATILE, ep_bytes = 8 * 64 * (WN + 4) * 4;
+        unsigned long long* const sums_tab = reinterpret_cast<unsigned long long*>(smem + (ring_bytes > ep_bytes ? ring_bytes : ep_bytes));
+        gt_epilogue<T, WM, WN, true, false, 4, 0>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane, sums_tab, img);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (uwave == 0) gt_flush_sums(sums_tab, reinterpret_cast<unsigned long long*>(p.ln_sums), img, BM, p.M, lane);
+    }
     else if (prefetch) gt_epilogue<T, WM, WN, false, false, 4, 1>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
     else gt_epilogue<T, WM, WN, false, false, 4, 0>(acc, ep, p, m0 + wm * WM, n0 + wn * WN, lane);
 }
@@ -264,7 +277,7 @@ template <typename T, bool SUMS, int BN>
 static void conv_pp_launch_one(const theia_gemm_args_t& a, const conv_taps_t& tp, hipStream_t stream) {
     constexpr int ring_bytes = 6 * BN * 64 + 2 * (256 * 64 + 2 * 32 * 64);
     constexpr int ep_bytes = 8 * 64 * (BN / 4 + 4) * 4;
-    constexpr int lds = ring_bytes > ep_bytes ? ring_bytes : ep_bytes;
+    constexpr int lds = (ring_bytes > ep_bytes ? ring_bytes : ep_bytes) + 64;  // + the workgroup's statistics table (SUMS)
     auto kern = gemm_conv_pp_kernel<T, SUMS, BN>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -246,8 +246,9 @@ __device__ __forceinline__ void gd_epilogue_body(gt_f32x4 (&acc)[4][FM], const t
 // T = output element type.  BIAS_IN_ACC: the kernel initialised the accumulators with the bias row (then it is not added again);
 // resid_in_acc: the same for the residual rows (act == NONE only).  SCALE: fp8 operands, accumulators are rescaled first.
 template <typename T, int FM, bool SUMS, bool SCALE, bool BIAS_IN_ACC>
-__device__ __forceinline__ void gd_epilogue(gt_f32x4 (&acc)[4][FM], const theia_gemm_args_t& p, const gd_rows_t& rw, int m_wave0,
-                                            int n_wave0, int lane, bool resid_in_acc) {
+__device__ __forceinline__ int gd_epilogue(gt_f32x4 (&acc)[4][FM], const theia_gemm_args_t& p, const gd_rows_t& rw, int m_wave0,
+                                           int n_wave0, int lane, bool resid_in_acc, unsigned long long* sums_tab = nullptr,
+                                           int m_tile0 = 0) {  // -> SUMS: the tile's first image (for gt_flush_sums), else 0
     const int frow = lane & 15, fg = lane >> 4;
     gd_ctx_t<T> cx;
     cx.O = reinterpret_cast<T*>(p.out);
@@ -271,12 +272,13 @@ __device__ __forceinline__ void gd_epilogue(gt_f32x4 (&acc)[4][FM], const theia_
     cx.dump = reinterpret_cast<T*>(g_gt_dump) + lane * 8;
     // per-image (sum, sum of squares) of the stored values: see gt_epilogue
     unsigned long long* const lsum = SUMS ? reinterpret_cast<unsigned long long*>(p.ln_sums) : nullptr;
-    int img0 = 0;
+    int img0 = 0, img_tile0 = 0;
     cx.m_split = 0;
     if constexpr (SUMS) {
         int dummy;
         img0 = gt_divmod24(m_wave0 < p.M ? m_wave0 : 0, rw.R, rw.rcp_R, dummy);
         cx.m_split = (img0 + 1) * rw.R;
+        img_tile0 = __builtin_amdgcn_readfirstlane(gt_divmod24(m_tile0 < p.M ? m_tile0 : 0, rw.R, rw.rcp_R, dummy));
     }
     cx.ls0 = cx.lq0 = cx.ls1 = cx.lq1 = 0.f;
     // the row prefetch costs 32 registers: the 160-row wave tile and the statistics epilogues (whose launches never carry an
@@ -303,13 +305,21 @@ __device__ __forceinline__ void gd_epilogue(gt_f32x4 (&acc)[4][FM], const theia_
         // 2^-24 fixed point in 64-bit integers: integer addition is associative, so the totals do not depend on the order in
         // which the waves arrive (bit-reproducible steps), and a wave's partial loses < 6e-8 absolute
         auto fx = [](float v) { return (unsigned long long)__double2ll_rn((double)v * 16777216.0); };
+        // The waves' partials meet in a table in LDS (4 images x (sum, sum of squares); LDS integer atomics) and ONE wave adds the tile's
+        // totals to global memory later (gd_flush_sums, after the workgroup's next barrier): 2-4 global atomics per tile instead of
+        // 16-32.  Device-scope atomics are performed at the memory side (the per-XCD L2s are not coherent with each other) and
+        // serialise per address: with one pair per wave they cost 70-105 us per launch on the 64x64 maps (285 -> 179 us at K = 768,
+        // profiles/r03_ab_ln_sums_atomics.txt).
         if (lane == 0 && m_wave0 < p.M) {
-            atomicAdd(lsum + 2 * img0, fx(ls0));
-            atomicAdd(lsum + 2 * img0 + 1, fx(lq0));
-            if ((int64_t)(img0 + 1) * rw.R < p.M) {  // a second image exists (its sums are zero when the tile did not reach it)
-                atomicAdd(lsum + 2 * (img0 + 1), fx(ls1));
-                atomicAdd(lsum + 2 * (img0 + 1) + 1, fx(lq1));
+            unsigned long long* t0 = sums_tab + 2 * (img0 - img_tile0);
+            atomicAdd(t0, fx(ls0));
+            atomicAdd(t0 + 1, fx(lq0));
+            if ((int64_t)(img0 + 1) * rw.R < p.M && img0 + 1 - img_tile0 < GT_SUMS_SLOTS) {  // a second image exists
+                atomicAdd(t0 + 2, fx(ls1));
+                atomicAdd(t0 + 3, fx(lq1));
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // performed before this wave reaches the barrier the flush waits behind
     }
+    return img_tile0;
 }

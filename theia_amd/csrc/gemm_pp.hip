@@ -379,6 +379,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
     //    K < 3 half-tiles: the draining path instead.
     constexpr int BIAS_LDS = NSTAGE * STAGE;
     const bool seamless = !resid_init && nh >= NSTAGE - 1;
+    // SUMS: the waves' per-image partials of a tile meet in this table; wave 0 adds the previous tile's totals to global memory right
+    // behind the barrier at the top of the next tile (every wave has left its epilogue by then) and clears the table -- the next
+    // LDS additions are a whole main loop of barriers away
+    unsigned long long* const sums_tab = reinterpret_cast<unsigned long long*>(smem + BIAS_LDS + 2048);
+    int flush_img0 = -1;  // image base of the tile whose totals are still in the table
+    if constexpr (SUMS) {
+        if (threadIdx.x < 2 * GT_SUMS_SLOTS) sums_tab[threadIdx.x] = 0ull;  // (first use: behind every barrier of the first main loop)
+    }
     for (int r = 0; r < my_tiles; ++r) {
         // Fragment addresses: rows 16 apart share the swizzle (pp_f looks at bits 2..3 of the row), so the FM A fragments / 4 B
         // fragments of a wave are 1 KiB apart: one lane-dependent offset each + immediates.  The reads are inline asm (see
@@ -390,6 +398,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         const uint32_t lane_b = smem_base + BM * 64 + (wn * WN + frow_) * 64 + ((fg_ ^ pp_f(frow_)) << 4);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if constexpr (SUMS) {
+            if (uwave == 0 && flush_img0 >= 0)
+                gt_flush_sums(sums_tab, reinterpret_cast<unsigned long long*>(p.ln_sums), flush_img0, p.map.rows_h * p.map.rows_w, p.M, threadIdx.x & 63);
+        }
         if (ugroup == 1) {  // group 1 runs one barrier behind group 0
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -440,7 +452,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         PP_PHASE(4 + 4 * r)
         {
             const gd_rows_t rw(p);
-            gd_epilogue<OutT, FM, SUMS, SCALE, BIAS_IN_ACC>(acc, p, rw, m0 + wm * WM, n0 + wn * WN, threadIdx.x & 63, resid_init);
+            const int it0 = gd_epilogue<OutT, FM, SUMS, SCALE, BIAS_IN_ACC>(acc, p, rw, m0 + wm * WM, n0 + wn * WN, threadIdx.x & 63, resid_init, sums_tab, m0);
+            if constexpr (SUMS) flush_img0 = it0;
         }
         PP_PHASE(5 + 4 * r)
         if (r + 1 < my_tiles) {
@@ -500,6 +513,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         }
         PP_PHASE(6 + 4 * r)
     }
+    if constexpr (SUMS) {  // the last tile's totals
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (uwave == 0 && flush_img0 >= 0)
+            gt_flush_sums(sums_tab, reinterpret_cast<unsigned long long*>(p.ln_sums), flush_img0, p.map.rows_h * p.map.rows_w, p.M, threadIdx.x & 63);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail fetches write LDS: let them land before the workgroup exits
 }
 
@@ -516,7 +535,7 @@ static int pp_num_cus() {
 
 template <typename T, int BM, bool TAPS, bool SUMS>
 static int pp_launch_one(const theia_gemm_args_t* a, hipStream_t stream) {
-    constexpr int lds = 4 * (BM + 256) * 64 + 2048;  // operand ring + two bias rows (this tile's, the next tile's)
+    constexpr int lds = 4 * (BM + 256) * 64 + 2048 + 64;  // operand ring + two bias rows (this tile's, the next tile's) + statistics table
     auto kern = gemm_nt_pp_kernel<T, BM, TAPS, SUMS>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -149,9 +149,20 @@ __device__ unsigned long long g_ep_trace[8][16];
 // PREF: 1 = the launch has a residual / aux_in row to prefetch (bf16), 0 = it has not (callers branch once, wave-uniformly, between
 // the two instantiations: without a prefetch the loop carries no vector-memory wait and no prefetch registers), -1 = decide at
 // run time inside whether to prefetch and wait at the end of every group regardless (the smaller kernels)
+constexpr int GT_SUMS_SLOTS = 4;  // images a tile of <= 320 rows can touch when an image has >= 160 rows: 3 (+1: a wave's empty second image)
+// One wave, after a workgroup barrier that follows every wave's epilogue of the tile: add the table to the per-image totals and clear it.
+__device__ __forceinline__ void gt_flush_sums(unsigned long long* sums_tab, unsigned long long* lsum, int img_tile0, int R, int M, int lane) {
+    if (lane < 2 * GT_SUMS_SLOTS) {
+        const unsigned long long v = sums_tab[lane];
+        sums_tab[lane] = 0ull;
+        const int img = img_tile0 + (lane >> 1);
+        if (v != 0ull && (int64_t)img * R < M) atomicAdd(lsum + 2 * img + (lane & 1), v);
+    }
+}
+
 template <typename T, int WM, int WN, bool SUMS = false, bool SCALE = false, int GPMAX = 4, int PREF = -1>
 __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], float* ep /* wave-private LDS */,
-                                            const theia_gemm_args_t& p, int m_wave0, int n_wave0, int lane) {
+                                            const theia_gemm_args_t& p, int m_wave0, int n_wave0, int lane, unsigned long long* sums_tab = nullptr, int img_tile0 = 0) {
     constexpr int FM = WM / 16, FN = WN / 16;
     constexpr int EP_PITCH = WN + 4;
     constexpr int EPH = WM > 64 ? 64 : WM;
@@ -416,7 +427,18 @@ __device__ __forceinline__ void gt_epilogue(gt_f32x4 (&acc)[WN / 16][WM / 16], f
         // 2^-24 fixed point in 64-bit integers: integer addition is associative, so the totals do not depend on the order in
         // which the waves arrive (bit-reproducible steps; float atomics were not), and a wave's partial loses < 6e-8 absolute
         auto fx = [](float v) { return (unsigned long long)__double2ll_rn((double)v * 16777216.0); };
-        if (lane == 0 && m_wave0 < p.M) {
+        if (sums_tab != nullptr) {  // workgroup-level combine in LDS, one wave flushes later (gt_flush_sums; see gemm_epi_direct.h)
+            if (lane == 0 && m_wave0 < p.M) {
+                unsigned long long* t0 = sums_tab + 2 * (img0 - img_tile0);
+                atomicAdd(t0, fx(ls0));
+                atomicAdd(t0 + 1, fx(lq0));
+                if ((int64_t)(img0 + 1) * R < p.M && img0 + 1 - img_tile0 < GT_SUMS_SLOTS) {
+                    atomicAdd(t0 + 2, fx(ls1));
+                    atomicAdd(t0 + 3, fx(lq1));
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (lane == 0 && m_wave0 < p.M) {
             atomicAdd(lsum + 2 * img0, fx(ls0));
             atomicAdd(lsum + 2 * img0 + 1, fx(lq0));
             if ((int64_t)(img0 + 1) * R < p.M) {  // a second image exists (its sums are zero when the tile did not reach it)
