@@ -299,7 +299,8 @@ size_t theia_layernorm_chw_workspace_bytes(int b, int64_t E);
 /* ------------------------------------------------------------------------------------------------
  * K4: multi-head self-attention softmax(Q K^T / sqrt(dh)) V, dh = 64, whole sequence per workgroup
  * (modeling_vit.py:164-189).  qkv: [b, n, 3*D] (q | k | v, heads contiguous inside each);  o: [b, n, D];
- * lse: f32 [b, h, n] (log-sum-exp of the scaled scores, saved for backward).
+ * lse: f32 [b, h, n] (log-sum-exp of the scaled scores, saved for backward).  delta_ws: f32 [b, h, n] scratch of the backward pass
+ * (theia_attention_bwd_workspace_bytes; the bf16 path for n <= 208 computes dQ, dK and dV in one kernel and does not touch it).
  * ---------------------------------------------------------------------------------------------- */
 int theia_attention_fwd(const void* qkv, void* o, float* lse, int b, int n, int h, int dtype, void* stream);
 int theia_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv,

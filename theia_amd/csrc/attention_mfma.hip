@@ -321,6 +321,199 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_kernel(const bf16_t* __
     }
 }
 
+// ================================================================================================ backward: one kernel
+// dQ, dK and dV of a head from ONE evaluation of S, P, dP and dS (the two-kernel form evaluates them twice), bit-reproducible:
+//   phase 0  Q and dO -> LDS, delta[q] = sum_d dO[q][d] * O[q][d] (8 lanes per row) -> LDS, lse -> LDS
+//   phase 1  a wave owns a 16-key tile (13 of the 16 waves): the dK / dV loop of the two-kernel form, and every dS tile it
+//            computes is also written to LDS as bf16 [query][key]
+//   phase 2  K -> LDS over Q; a wave owns a 16-query tile: dQ = dS K with dS read back from LDS as the packed k-slot-permuted
+//            operand the dQ kernel builds in registers -- a fixed summation order, no atomics.
+// LDS: Q, dO 2 x 31.5 KB + dS 208 x 456 B = 92.6 KB + lse / delta 1.8 KB = 157.4 KB: one 16-wave workgroup per CU (the same 16 waves
+// per CU as two 8-wave workgroups of the two-kernel form).
+__device__ __forceinline__ void am_unpack8(const uint4& a, float (&v)[8]) {
+    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+constexpr int AF_DS_PITCH = 456;   // bytes per dS row: 224 keys x 2 B + 8 (row starts fall on distinct even banks)
+constexpr int AF_DS_ROWS = 208;
+constexpr int AF_THREADS = 1024;
+
+__global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                                    const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                                    bf16_t* __restrict__ dqkv, int n, int h, int nheads) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    char* sQ = sm;                                   // [224][144]; phase 2: K
+    char* sG = sm + AM_ROWS * AM_PITCH;              // [224][144]  dO
+    char* sDS = sm + 2 * AM_ROWS * AM_PITCH;         // [208][456]  dS (bf16, scaled), keys 208..223 zero
+    float* sL = reinterpret_cast<float*>(sDS + AF_DS_ROWS * AF_DS_PITCH);   // [224] lse * log2e (+inf beyond n)
+    float* sD = sL + AM_ROWS;                                              // [224] delta
+    const int D = h * 64;
+    const int64_t rs = 3 * (int64_t)D;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, g = lane >> 4;
+    if (tid < AF_DS_ROWS) {  // the key columns no wave writes (once: nothing else touches them)
+        *reinterpret_cast<uint4*>(sDS + tid * AF_DS_PITCH + 416) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(sDS + tid * AF_DS_PITCH + 432) = make_uint4(0, 0, 0, 0);
+    }
+    // (A persistent form -- one workgroup per CU walking over heads, the next head's Q / dO / O and this head's K requested into
+    //  registers ahead of time -- was measured: 172 us against 134 for this one; its 26 staging registers on top of phase 1 spill.)
+    uint4 xq[2], xg[2], xo[2];
+    float xl[2];
+    const int bh = blockIdx.x;
+    {
+        const int bi = bh / h, hi = bh % h;
+        const bf16_t* base = qkv + (int64_t)bi * n * rs + hi * 64;
+        const bf16_t* gbase = d_o + (int64_t)bi * n * D + hi * 64;
+        const bf16_t* obase = o + (int64_t)bi * n * D + hi * 64;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int v = tid + it * AF_THREADS, r = v >> 3, c = v & 7;
+            xq[it] = xg[it] = xo[it] = make_uint4(0, 0, 0, 0);
+            xl[it] = INFINITY;
+            if (r < n && r < AM_ROWS) {
+                xq[it] = *reinterpret_cast<const uint4*>(base + r * rs + c * 8);
+                xg[it] = *reinterpret_cast<const uint4*>(gbase + (int64_t)r * D + c * 8);
+                xo[it] = *reinterpret_cast<const uint4*>(obase + (int64_t)r * D + c * 8);
+                if (c == 0) xl[it] = lse[(int64_t)bh * n + r] * AM_LOG2E;
+            }
+        }
+    }
+    {
+        const int bi = bh / h, hi = bh % h;
+        const bf16_t* base = qkv + (int64_t)bi * n * rs + hi * 64;
+        // ---- phase 0: registers -> LDS, delta
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int v = tid + it * AF_THREADS, r = v >> 3, c = v & 7;
+            float a8[8], b8[8], part = 0.f;
+            am_unpack8(xg[it], a8);
+            am_unpack8(xo[it], b8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += a8[j] * b8[j];
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            if (r < AM_ROWS) {
+                *reinterpret_cast<uint4*>(sQ + r * AM_PITCH + c * 16) = xq[it];
+                *reinterpret_cast<uint4*>(sG + r * AM_PITCH + c * 16) = xg[it];
+                if (c == 0) {
+                    sD[r] = part;   // rows >= n: 0
+                    sL[r] = xl[it];  // rows >= n: +inf
+                }
+            }
+        }
+        __syncthreads();
+        // this head's K pieces for phase 2, requested now
+        uint4 xk[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int v = tid + it * AF_THREADS, r = v >> 3, c = v & 7;
+            xk[it] = make_uint4(0, 0, 0, 0);
+            if (r < n && r < AM_ROWS) xk[it] = *reinterpret_cast<const uint4*>(base + r * rs + D + c * 8);
+        }
+        const int mytile = (wave + bh) & 15;  // 13 of the 16 waves own a tile; which three idle rotates with the head
+        // ---- phase 1: dK, dV (+ dS -> LDS)
+        if (mytile < AM_TILES) {
+            const int krow = mytile * 16 + l16;
+            const bool kok = krow < n;
+            uint4 kf[2], vf[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                kf[kk] = vf[kk] = make_uint4(0, 0, 0, 0);
+                if (kok) {
+                    kf[kk] = *reinterpret_cast<const uint4*>(base + krow * rs + D + kk * 32 + g * 8);
+                    vf[kk] = *reinterpret_cast<const uint4*>(base + krow * rs + 2 * D + kk * 32 + g * 8);
+                }
+            }
+            am_f32x4 dk[4], dv[4];
+#pragma unroll
+            for (int df = 0; df < 4; ++df) dk[df] = dv[df] = (am_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int ks = 0; ks < AM_KSTEPS; ++ks) {
+                am_f32x4 p[2], dsv[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int q0 = (2 * ks + t) * 16;
+                    am_f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+                    am_mma(sa, am_nat(sQ, q0, 0, lane), kf[0]);
+                    am_mma(sa, am_nat(sQ, q0, 1, lane), kf[1]);
+                    am_mma(da, am_nat(sG, q0, 0, lane), vf[0]);
+                    am_mma(da, am_nat(sG, q0, 1, lane), vf[1]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qi = q0 + g * 4 + r;
+                        const float pv = kok ? am_exp2(fmaf(sa[r], AM_C, -sL[qi])) : 0.f;  // keys beyond n: no probability
+                        p[t][r] = pv;
+                        dsv[t][r] = pv * (da[r] - sD[qi]) * 0.125f;
+                    }
+                }
+                const uint4 pb = am_pack(p[0], p[1]), sb = am_pack(dsv[0], dsv[1]);
+                // dS[q][k] for phase 2: this lane holds (q0 + 4g + r, key krow) -- sb.x/.y are tile t = 0 (r = 0,1 | 2,3), .z/.w tile t = 1
+                {
+                    uint16_t* w0 = reinterpret_cast<uint16_t*>(sDS + krow * 2 + (32 * ks + g * 4) * AF_DS_PITCH);
+                    constexpr int rp = AF_DS_PITCH / 2;  // row pitch in 16-bit units
+                    w0[0 * rp] = (uint16_t)(sb.x & 0xffffu);
+                    w0[1 * rp] = (uint16_t)(sb.x >> 16);
+                    w0[2 * rp] = (uint16_t)(sb.y & 0xffffu);
+                    w0[3 * rp] = (uint16_t)(sb.y >> 16);
+                    if (2 * ks + 1 < AM_TILES) {  // (the 14th query tile does not exist)
+                        uint16_t* w1 = w0 + 16 * rp;
+                        w1[0 * rp] = (uint16_t)(sb.z & 0xffffu);
+                        w1[1 * rp] = (uint16_t)(sb.z >> 16);
+                        w1[2 * rp] = (uint16_t)(sb.w & 0xffffu);
+                        w1[3 * rp] = (uint16_t)(sb.w >> 16);
+                    }
+                }
+#pragma unroll
+                for (int df = 0; df < 4; ++df) {
+                    am_mma(dv[df], am_tr(sG, ks, df, lane), pb);
+                    am_mma(dk[df], am_tr(sQ, ks, df, lane), sb);
+                }
+            }
+            if (kok) {
+                bf16_t* drow = dqkv + ((int64_t)bi * n + krow) * rs + hi * 64 + g * 4;
+#pragma unroll
+                for (int df = 0; df < 4; ++df) {
+                    am_store4(drow + D + df * 16, dk[df], 1.0f);
+                    am_store4(drow + 2 * D + df * 16, dv[df], 1.0f);
+                }
+            }
+        }
+        __syncthreads();  // every wave has finished reading Q / dO and writing dS
+        // ---- phase 2: K -> LDS (over Q), dQ = dS K
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int v = tid + it * AF_THREADS, r = v >> 3, c = v & 7;
+            if (r < AM_ROWS) *reinterpret_cast<uint4*>(sQ + r * AM_PITCH + c * 16) = xk[it];
+        }
+        __syncthreads();
+        if (mytile < AM_TILES) {
+            const int qrow = mytile * 16 + l16;
+            am_f32x4 dq[4];
+#pragma unroll
+            for (int df = 0; df < 4; ++df) dq[df] = (am_f32x4){0.f, 0.f, 0.f, 0.f};
+            const char* drow_l = sDS + qrow * AF_DS_PITCH + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < AM_KSTEPS; ++ks) {
+                const uint2 lo = *reinterpret_cast<const uint2*>(drow_l + ks * 64), hi2 = *reinterpret_cast<const uint2*>(drow_l + ks * 64 + 32);
+                const uint4 sb = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+#pragma unroll
+                for (int df = 0; df < 4; ++df) am_mma(dq[df], am_tr(sQ, ks, df, lane), sb);
+            }
+            if (qrow < n) {
+                bf16_t* drow = dqkv + ((int64_t)bi * n + qrow) * rs + hi * 64 + g * 4;
+#pragma unroll
+                for (int df = 0; df < 4; ++df) am_store4(drow + df * 16, dq[df], 1.0f);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers (called from attention.hip)
 static void am_set_lds(const void* kern, int bytes) {
     static const void* seen[8];
@@ -343,6 +536,19 @@ int theia_attention_fwd_mfma(const void* qkv, void* o, float* lse, int b, int n,
 
 int theia_attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* delta,
                              int b, int n, int h, hipStream_t s) {
+    static int fused = -1;  // THEIA_ATTN_BWD=split: the two-kernel form (A/B switch)
+    if (fused < 0) {
+        const char* e = getenv("THEIA_ATTN_BWD");
+        fused = (e != nullptr && strcmp(e, "split") == 0) ? 0 : 1;
+    }
+    if (fused) {
+        const int ldsf = 2 * AM_ROWS * AM_PITCH + AF_DS_ROWS * AF_DS_PITCH + 2 * AM_ROWS * (int)sizeof(float);
+        am_set_lds(reinterpret_cast<const void*>(attn_bwd_fused_kernel), ldsf);
+        hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(b * h), dim3(AF_THREADS), ldsf, s, (const bf16_t*)qkv, (const bf16_t*)o,
+                           (const bf16_t*)d_o, lse, (bf16_t*)dqkv, n, h, b * h);
+        THEIA_CHECK_LAUNCH("theia_attention_bwd(fused mfma)");
+        return THEIA_OK;
+    }
     const int lds1 = (AM_ROWS + 208) * AM_PITCH;
     const int lds2 = 2 * AM_ROWS * AM_PITCH + 2 * AM_ROWS * (int)sizeof(float);
     am_set_lds(reinterpret_cast<const void*>(attn_bwd_dq_mfma_kernel<true>), lds1);
