@@ -578,6 +578,18 @@ def test_attention_fwd_bwd(dt, hh):
     assert relerr(dqkv.float().view(b, n, 3 * D), r.grad) < (1e-4 if dt == torch.float32 else 2e-2)
 
 
+def test_attention_bwd_two_kernel_form_in_a_fresh_process():
+    """The default bf16 backward is the single kernel (attn_bwd_fused_kernel); the two-kernel form stays selectable with
+    THEIA_ATTN_BWD=split (read once per process): the same attention tests in a child process with that switch."""
+    import subprocess
+    import sys
+    env = dict(os.environ, THEIA_ATTN_BWD="split")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_ops_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "test_attention_fwd_bwd or per_tensor_bound"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("sharp", [1.0, 3.0])
 def test_attention_bwd_per_tensor_bound_at_batch_8(sharp):
     """The per-kernel bound behind the model-level bf16 gradient gates: the attention kernels alone, bf16, b = 8 x 12 heads x 197
