@@ -124,7 +124,7 @@ def test_linear_bias_epilogues(dt, M, N, K, tile):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(197 * 4, 192, 192), (1000, 128, 256), (4096 + 37, 64, 64), (513, 1280, 192), (300, 32, 384),
+@pytest.mark.parametrize("M,N,K", [(197 * 4, 192, 192), (1000, 128, 256), (4096 + 37, 64, 64), (513, 1280, 192), (300, 32, 384), (2049, 24, 128), (777, 8, 64),
                                    (197 * 9, 768, 768), (2000, 3072, 768), (5000, 256, 768), (96, 1280, 768)])
 def test_linear_wgrad_and_colsum(dt, M, N, K):
     from theia_amd import ops

@@ -613,19 +613,22 @@ static int colsum_rowblocks(int64_t M) {
 }
 extern "C" size_t theia_colsum_workspace_bytes(int64_t M, int N) { return (size_t)colsum_rowblocks(M) * N * sizeof(float); }
 
-template <typename T>
+// CV: 16-byte column vectors per block (32: 256 columns x 8 row lanes; 4: 32 columns x 64 row lanes -- for the narrow matrices of the
+// heads' last Linear (N = 32), where 28 of 32 column lanes of the wide form had nothing to do: 176 -> ~20 us on [524288, 32])
+template <typename T, int CV>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t M, int N, int64_t ld,
                                                      float* __restrict__ part, int rows_per_block) {
-    __shared__ float red[8][32][9];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int cv = blockIdx.x * 32 + cl;  // column vector index
+    constexpr int RL = 256 / CV;
+    __shared__ float red[RL][CV][9];
+    const int cl = threadIdx.x % CV, rl = threadIdx.x / CV;
+    const int cv = blockIdx.x * CV + cl;  // column vector index
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     float a[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = 0.f;
     if (cv * 8 < N) {
         const int64_t r1 = min(M, r0 + rows_per_block);
-        for (int64_t r = r0 + rl; r < r1; r += 8) {
+        for (int64_t r = r0 + rl; r < r1; r += RL) {
             float v[8];
             load8(x + r * ld + cv * 8, v);
 #pragma unroll
@@ -640,8 +643,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s += red[k][cl][j];
+#pragma unroll 8
+            for (int k = 0; k < RL; ++k) s += red[k][cl][j];
             o[j] = s;
         }
         store8(part + (int64_t)blockIdx.y * N + cv * 8, o);
@@ -668,9 +671,15 @@ extern "C" int theia_colsum(const void* x, int64_t M, int N, int64_t ld, float* 
     THEIA_CHECK_ARG(x && out && workspace && M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0, "theia_colsum: bad args (N, ld multiples of 8)");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int rb = colsum_rowblocks(M), rpb = colsum_rows_per_block(M);
-    const dim3 grid((N / 8 + 31) / 32, rb);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, M, N, ld, workspace, rpb),
-               hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, M, N, ld, workspace, rpb), "theia_colsum");
+    if (N <= 32) {
+        const dim3 grid((N / 8 + 3) / 4, rb);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)x, M, N, ld, workspace, rpb),
+                   hipLaunchKernelGGL((colsum_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)x, M, N, ld, workspace, rpb), "theia_colsum");
+    } else {
+        const dim3 grid((N / 8 + 31) / 32, rb);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<bf16_t, 32>), grid, dim3(256), 0, s, (const bf16_t*)x, M, N, ld, workspace, rpb),
+                   hipLaunchKernelGGL((colsum_kernel<float, 32>), grid, dim3(256), 0, s, (const float*)x, M, N, ld, workspace, rpb), "theia_colsum");
+    }
     THEIA_CHECK_LAUNCH("theia_colsum");
     hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, s, workspace, rb, N, out, accumulate);
     THEIA_CHECK_LAUNCH("theia_colsum(final)");
