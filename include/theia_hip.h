@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define THEIA_ABI_VERSION 5
+#define THEIA_ABI_VERSION 6
 
 enum { THEIA_OK = 0, THEIA_ERR_INVALID = -1, THEIA_ERR_LAUNCH = -2, THEIA_ERR_UNSUPPORTED = -3 };
 enum { THEIA_F32 = 0, THEIA_BF16 = 1,
@@ -294,6 +294,12 @@ int theia_layernorm_chw_fwd_sums(const void* x, const float* gamma, const float*
 int theia_layernorm_chw_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
                             float* dgamma, float* dbeta, float* workspace, int b, int64_t E, int relu_mask,
                             int accumulate, int dtype, void* stream);
+/* The same, and dxsum[c] (+)= sum over samples and pixels of dx[s, pixel, c] (f32 [C], C a multiple of 8 dividing E, channels innermost):
+ * the bias gradient of the convolution that produced x (adapter_heads.py:304-327: Conv2d / ConvTranspose2d -> LayerNorm) without a
+ * second pass over dx.  dxsum == NULL: plain theia_layernorm_chw_bwd. */
+int theia_layernorm_chw_bwd_colsum(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
+                                   float* dgamma, float* dbeta, float* workspace, int b, int64_t E, int relu_mask,
+                                   int accumulate, float* dxsum, int C, int dxsum_accumulate, int dtype, void* stream);
 size_t theia_layernorm_chw_workspace_bytes(int b, int64_t E);
 
 /* ------------------------------------------------------------------------------------------------

@@ -42,7 +42,7 @@ def rnd(x, dt):
 def test_library_loads_and_abi():
     from theia_amd import _native as N
     lib = N.lib()
-    assert lib.theia_abi_version() == N.ABI_VERSION == 5
+    assert lib.theia_abi_version() == N.ABI_VERSION == 6
     assert lib.theia_dtype_size(N.BF16) == 2
 
 
@@ -549,6 +549,15 @@ def test_layernorm_chw(dt, C, H):
     # relu mask folds d relu: x == relu(pre) so (x > 0) selects the live units
     dxm = ops.layernorm_chw_bwd(dy.to(dev, dt).view(b, E), xd, g_nhwc, stats, dg, ds, relu_mask=True, accumulate=False)
     assert relerr(dxm.float().view(b, H, H, C), xr.grad * (rnd(x, dt) > 0)) < (1e-4 if dt == torch.float32 else 2e-2)
+    # the same pass also hands out the column sums of dx (the producing convolution's bias gradient): exactly the sums of the dx it
+    # stores (f32 accumulation of the stored values), with and without accumulation
+    cs = torch.full((C,), 0.25, dtype=torch.float32, device=dev)
+    dx2 = ops.layernorm_chw_bwd(dy.to(dev, dt).view(b, E), xd, g_nhwc, stats, dg, ds, relu_mask=True, accumulate=False, dxsum=(cs, True))
+    assert torch.equal(dx2, dxm)
+    want = dxm.float().view(-1, C).double().sum(0)
+    assert relerr(cs - 0.25, want) < 1e-5
+    ops.layernorm_chw_bwd(dy.to(dev, dt).view(b, E), xd, g_nhwc, stats, dg, ds, relu_mask=True, accumulate=False, dxsum=(cs, False))
+    assert relerr(cs, want) < 1e-5
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtheia_hip.so")
 
 F32, BF16, FP8 = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_MUL_DGELU, ACT_MUL_DRELU = 0, 1, 2, 3, 4
 MAX_TAPS = 9
 
@@ -110,6 +110,7 @@ _SIGNATURES = {
     "theia_layernorm_chw_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "theia_layernorm_chw_fwd_sums": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "theia_layernorm_chw_bwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "theia_layernorm_chw_bwd_colsum": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "theia_layernorm_chw_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
     "theia_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "theia_attention_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -238,8 +238,9 @@ static int chw_groups(int b, int64_t E) {
 extern "C" size_t theia_layernorm_chw_workspace_bytes(int b, int64_t E) {
     const size_t stats = (((size_t)b * chw_chunks(E) * 2 + 63) / 64) * 64;  // floats: per-chunk partial sums
     const size_t dstat = (((size_t)b * 2 + 63) / 64) * 64;                    // floats: per-sample backward means
-    const size_t parts = (size_t)chw_groups(b, E) * 2 * E;                   // floats: per-group affine-grad partials
-    return (stats + dstat + parts) * sizeof(float);
+    const size_t parts = (size_t)chw_groups(b, E) * 3 * E;                   // floats: per-group affine-grad partials (+ dx sums)
+    const size_t csum = (size_t)chw_groups(b, E) * E + 64;  // floats: column-sum partials of the dx sums (<= min(256, rows) x C <= ng x E)
+    return (stats + dstat + parts + csum) * sizeof(float);
 }
 
 // partial (sum a, sum b) per (sample, chunk).  MODE 0: a = x, b = x*x.  MODE 1: a = dy*g, b = dy*g*xhat.
@@ -423,20 +424,23 @@ extern "C" int theia_layernorm_chw_fwd_sums(const void* x, const float* gamma, c
 }
 
 // dx for a group of samples + partial affine gradients of that group
-template <typename T>
+// DXSUM: also the group's sum over samples of dx per element (part3[grp][E]) -- the producing convolution's bias gradient is its
+// sum over pixels, so the 805 MB re-read of dx by a column-sum kernel (64x64 maps) becomes a 12.6 MB one
+template <typename T, bool DXSUM>
 __global__ __launch_bounds__(256) void chw_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                       const float* __restrict__ gamma, const float* __restrict__ stats,
                                                       const float* __restrict__ dstat, T* __restrict__ dx,
-                                                      float* __restrict__ part, int b, int64_t E, int ngroups, int relu_mask) {
+                                                      float* __restrict__ part, float* __restrict__ part3, int b, int64_t E, int ngroups,
+                                                      int relu_mask) {
     const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (e >= E) return;
     const int grp = blockIdx.y;
     const int per = (b + ngroups - 1) / ngroups;
     const int s0 = grp * per, s1 = min(b, s0 + per);
-    float g8[8], ag[8], ab[8];
+    float g8[8], ag[8], ab[8], ac[8];
     load8(gamma + e, g8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ag[j] = ab[j] = 0.f;
+    for (int j = 0; j < 8; ++j) ag[j] = ab[j] = ac[j] = 0.f;
     for (int s = s0; s < s1; ++s) {
         const float mu = stats[2 * s], rs = stats[2 * s + 1];
         const float m1 = dstat[2 * s], m2 = dstat[2 * s + 1];
@@ -453,16 +457,30 @@ __global__ __launch_bounds__(256) void chw_bwd_kernel(const T* __restrict__ dy, 
             o[j] = d;
         }
         store8(dx + (int64_t)s * E + e, o);
+        if constexpr (DXSUM) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ac[j] += sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(o[j])) : o[j];  // the value as stored
+        }
     }
     float* pg = part + (int64_t)grp * 2 * E;
     store8(pg + e, ag);
     store8(pg + E + e, ab);
+    if constexpr (DXSUM) store8(part3 + (int64_t)grp * E + e, ac);
 }
 
+extern "C" int theia_layernorm_chw_bwd_colsum(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
+                                              float* dgamma, float* dbeta, float* workspace, int b, int64_t E, int relu_mask,
+                                              int accumulate, float* dxsum, int C, int dxsum_accumulate, int dtype, void* stream);
 extern "C" int theia_layernorm_chw_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
                                        float* dgamma, float* dbeta, float* workspace, int b, int64_t E, int relu_mask,
                                        int accumulate, int dtype, void* stream) {
+    return theia_layernorm_chw_bwd_colsum(dy, x, gamma, stats, dx, dgamma, dbeta, workspace, b, E, relu_mask, accumulate, nullptr, 0, 0, dtype, stream);
+}
+extern "C" int theia_layernorm_chw_bwd_colsum(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
+                                              float* dgamma, float* dbeta, float* workspace, int b, int64_t E, int relu_mask,
+                                              int accumulate, float* dxsum, int C, int dxsum_accumulate, int dtype, void* stream) {
     THEIA_CHECK_ARG(dy && x && gamma && stats && dx && dgamma && dbeta && workspace, "theia_layernorm_chw_bwd: null pointer");
+    THEIA_CHECK_ARG(dxsum == nullptr || (C >= 8 && C % 8 == 0 && E % C == 0), "theia_layernorm_chw_bwd_colsum: C=%d must be a multiple of 8 dividing E", C);
     THEIA_CHECK_ARG(b > 0 && E > 0 && E % 8 == 0, "theia_layernorm_chw_bwd: bad E");
     THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16, "theia_layernorm_chw_bwd: bad dtype");
     const int nch = chw_chunks(E);
@@ -471,6 +489,8 @@ extern "C" int theia_layernorm_chw_bwd(const void* dy, const void* x, const floa
     float* part_stats = workspace;
     float* dstat = part_stats + (((size_t)b * nch * 2 + 63) / 64) * 64;
     float* parts = dstat + (((size_t)b * 2 + 63) / 64) * 64;
+    float* parts3 = parts + (size_t)ng * 2 * E;   // [ng][E]: per-group sums of dx over the group's samples
+    float* csum_ws = parts3 + (size_t)ng * E;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int ngp = chw_sample_groups(b, nch);
     if (dtype == THEIA_BF16)
@@ -481,11 +501,18 @@ extern "C" int theia_layernorm_chw_bwd(const void* dy, const void* x, const floa
     hipLaunchKernelGGL(chw_finalize_kernel<1>, dim3((b + 63) / 64), dim3(64), 0, s, part_stats, dstat, b, nch, E, 0.f);
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_bwd(finalize)");
     const dim3 grid((unsigned)((E / 8 + 255) / 256), ng);
-    if (dtype == THEIA_BF16)
-        hipLaunchKernelGGL(chw_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, stats, dstat, (bf16_t*)dx, parts, b, E, ng, relu_mask);
-    else
-        hipLaunchKernelGGL(chw_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, stats, dstat, (float*)dx, parts, b, E, ng, relu_mask);
+    if (dtype == THEIA_BF16) {
+        if (dxsum) hipLaunchKernelGGL((chw_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, stats, dstat, (bf16_t*)dx, parts, parts3, b, E, ng, relu_mask);
+        else hipLaunchKernelGGL((chw_bwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, stats, dstat, (bf16_t*)dx, parts, parts3, b, E, ng, relu_mask);
+    } else {
+        if (dxsum) hipLaunchKernelGGL((chw_bwd_kernel<float, true>), grid, dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, stats, dstat, (float*)dx, parts, parts3, b, E, ng, relu_mask);
+        else hipLaunchKernelGGL((chw_bwd_kernel<float, false>), grid, dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, stats, dstat, (float*)dx, parts, parts3, b, E, ng, relu_mask);
+    }
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_bwd(dx)");
+    if (dxsum) {  // [ng * H*W][C] f32 -> [C]
+        const int rc = theia_colsum(parts3, (int64_t)ng * (E / C), C, C, dxsum, csum_ws, dxsum_accumulate, THEIA_F32, stream);
+        if (rc) return rc;
+    }
     // reduce partials: columns [0,E) -> dgamma, [E,2E) -> dbeta
     const int64_t ncol = 2 * E;
     hipLaunchKernelGGL(partial_reduce_kernel<64>, dim3((unsigned)((ncol + 63) / 64)), dim3(256), 0, s, parts, ng, (int)ncol,

@@ -893,20 +893,24 @@ class StudentEngine:
 
                 side.run(lambda: ops.linear_wgrad(dy, x, gw, accw, side.ws, bias=(gb, accb)), dy, x)
 
-            def conv_grads(dy2d, x, mod, plan, mtot):
-                """dy2d [M_total, C] is the conv output gradient, x the conv input (flat NHWC); side stream like the ViT's."""
+            def conv_grads(dy2d, x, mod, plan, mtot, bias_done=False):
+                """dy2d [M_total, C] is the conv output gradient, x the conv input (flat NHWC); side stream like the ViT's.
+                bias_done: the bias gradient came out of the LayerNorm backward that produced dy2d (ln_bwd(bias_of=))."""
                 if not train:
                     return
-                gb, accb = self._grad(mod.bias)
+                bias = None if bias_done else self._grad(mod.bias)
                 gw, accw = self._grad(mod.weight)
 
-                side.run(lambda: ops.conv_wgrad(plan, dy2d, x, b, C, gw, accw, side.ws, bias=(gb, accb)), dy2d, x)
+                side.run(lambda: ops.conv_wgrad(plan, dy2d, x, b, C, gw, accw, side.ws, bias=bias), dy2d, x)
 
-            def ln_bwd(dy, x, stats, idx, hw, relu_mask):
+            def ln_bwd(dy, x, stats, idx, hw, relu_mask, bias_of=None):
+                """bias_of: the convolution that produced x, when its weight-gradient GEMM cannot carry the bias gradient (the stride-2
+                transposed convolutions reduce over input pixels): its bias gradient = the column sums of dx, out of this pass."""
                 E = hw * hw * C
                 tmp_g = ws[chw_need: chw_need + E]
                 tmp_b = ws[chw_need + E3: chw_need + E3 + E]
-                dx = ops.layernorm_chw_bwd(dy, x, oc[pf + f"ln{idx}.g"], stats, tmp_g, tmp_b, relu_mask, False, ws[:chw_need])
+                dxsum = self._grad(bias_of.bias) if (train and bias_of is not None) else None
+                dx = ops.layernorm_chw_bwd(dy, x, oc[pf + f"ln{idx}.g"], stats, tmp_g, tmp_b, relu_mask, False, ws[:chw_need], dxsum=dxsum)
                 if train:
                     g, acc = self._grad(hm.adapter[idx].weight)
                     ops.transpose_acc(tmp_g, g, hw * hw, C, acc)  # [HW][C] (NHWC reduction order) -> [C][H][W]
@@ -925,14 +929,15 @@ class StudentEngine:
             lin_grads(dp, v3.view(b * s2 * s2, C), hm.adapter["8"])
             dv3 = self._mm(dp, pf + "w8T")
             del v3
-            du3 = ln_bwd(dv3.view(b, E3), u3, st6, "6", s2, True)
+            swapped4, swapped1 = self._plan(p4).wgrad_swapped, self._plan(p1).wgrad_swapped
+            du3 = ln_bwd(dv3.view(b, E3), u3, st6, "6", s2, True, bias_of=hm.adapter["4"] if swapped4 else None)
             del dv3, u3
-            conv_grads(du3.view(b * s2 * s2, C), v2, hm.adapter["4"], self._plan(p4), b * s2 * s2)
+            conv_grads(du3.view(b * s2 * s2, C), v2, hm.adapter["4"], self._plan(p4), b * s2 * s2, bias_done=swapped4)
             dv2 = conv_dgrad(du3, pf + "c4.wd", self._plan(p4), torch.empty(b, s1 * s1 * C, dtype=T, device=dev))
             del du3, v2
-            du2 = ln_bwd(dv2, u2, st3, "3", s1, True)
+            du2 = ln_bwd(dv2, u2, st3, "3", s1, True, bias_of=hm.adapter["1"] if swapped1 else None)
             del dv2, u2
-            conv_grads(du2.view(b * s1 * s1, C), v1, hm.adapter["1"], self._plan(p1), b * s1 * s1)
+            conv_grads(du2.view(b * s1 * s1, C), v1, hm.adapter["1"], self._plan(p1), b * s1 * s1, bias_done=swapped1)
             dv1 = conv_dgrad(du2, pf + "c1.wd", self._plan(p1), torch.empty(b, 256 * C, dtype=T, device=dev))
             del du2, v1
             du1 = ln_bwd(dv1, u1, st0, "0", s0, False)

@@ -503,15 +503,20 @@ def layernorm_chw_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, 
     return y, stats
 
 
-def layernorm_chw_bwd(dy, x, gamma, stats, dgamma, dbeta, relu_mask: bool, accumulate: bool, ws: Optional[torch.Tensor] = None):
+def layernorm_chw_bwd(dy, x, gamma, stats, dgamma, dbeta, relu_mask: bool, accumulate: bool, ws: Optional[torch.Tensor] = None,
+                      dxsum: Optional[Tuple[torch.Tensor, bool]] = None):
+    """dxsum = (f32 [C], accumulate): also dxsum[c] (+)= sum over samples and pixels of dx -- the bias gradient of the convolution that
+    produced x, from the pass that writes dx (theia_layernorm_chw_bwd_colsum)."""
     b, E = x.shape
     dx = torch.empty_like(x)
     need = N.lib().theia_layernorm_chw_workspace_bytes(b, E) // 4
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.float32, device=x.device)
-    N.check(N.lib().theia_layernorm_chw_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats.data_ptr(), dx.data_ptr(),
-                                            dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), b, E, int(relu_mask),
-                                            int(accumulate), _dt(x), N.stream_ptr()), "theia_layernorm_chw_bwd")
+    ds, dC, dacc = (dxsum[0].data_ptr(), dxsum[0].numel(), int(dxsum[1])) if dxsum is not None else (None, 0, 0)
+    assert dxsum is None or dxsum[0].dtype == torch.float32
+    N.check(N.lib().theia_layernorm_chw_bwd_colsum(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats.data_ptr(), dx.data_ptr(),
+                                                   dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), b, E, int(relu_mask),
+                                                   int(accumulate), ds, dC, dacc, _dt(x), N.stream_ptr()), "theia_layernorm_chw_bwd")
     return dx
 
 
