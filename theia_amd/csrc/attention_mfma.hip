@@ -344,7 +344,7 @@ constexpr int AF_THREADS = 1024;
 
 __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                     const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
-                                                                    bf16_t* __restrict__ dqkv, int n, int h, int nheads) {
+                                                                    bf16_t* __restrict__ dqkv, int n, int h) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     char* sQ = sm;                                   // [224][144]; phase 2: K
     char* sG = sm + AM_ROWS * AM_PITCH;              // [224][144]  dO
@@ -545,7 +545,7 @@ int theia_attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, co
         const int ldsf = 2 * AM_ROWS * AM_PITCH + AF_DS_ROWS * AF_DS_PITCH + 2 * AM_ROWS * (int)sizeof(float);
         am_set_lds(reinterpret_cast<const void*>(attn_bwd_fused_kernel), ldsf);
         hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(b * h), dim3(AF_THREADS), ldsf, s, (const bf16_t*)qkv, (const bf16_t*)o,
-                           (const bf16_t*)d_o, lse, (bf16_t*)dqkv, n, h, b * h);
+                           (const bf16_t*)d_o, lse, (bf16_t*)dqkv, n, h);
         THEIA_CHECK_LAUNCH("theia_attention_bwd(fused mfma)");
         return THEIA_OK;
     }
