@@ -245,34 +245,36 @@ def test_conv_family_fwd_dgrad_wgrad(dt, kind, C, tile):
     assert relerr(gb2 - 0.5, gyr.double().sum((0, 1, 2))) < 1e-5
 
 
-@pytest.mark.parametrize("kind", ["conv_p1", "convT_s1"])
+@pytest.mark.parametrize("kind", ["conv_p1", "convT_s1", "conv_p1_8x8"])
 @pytest.mark.parametrize("b", [29, 37])
 def test_conv_wgrad_periodic_rows_with_uneven_splits(b, kind):
-    """The weight-gradient kernel's periodic row mode (16x16 output maps: a step of 32 rows is two image rows, so there is no x wrap,
-    the y wrap falls on the step that re-enters an image, and whether a tap's input pixel exists repeats every 8 steps; each staged row
-    tests one bit of a mask built once).  conv_p1: dense 16x16 input; convT_s1: 14x14 input under a 16x16 output (non-zero image-wrap
-    constant on the input side).  b = 29 / 37 images of 256 channels give 28 splits of 9 / 11 steps, so the splits start at every
-    phase of the period (the 3-image case of test_conv_family_fwd_dgrad_wgrad only ever starts at phase 0), and the last split is
-    ragged.  Against the oracle's shifted-matmul convolution, for the bf16 ping-pong kernel and -- same rounded inputs -- the exact-f32
-    2-stage kernel."""
+    """The weight-gradient kernel's periodic row mode (images of a multiple of 32 pixels whose width divides 32: a step of 32 rows
+    never wraps in x, the y wrap falls on the step that re-enters an image, and whether a tap's input pixel exists repeats with the
+    image's steps; each staged row tests one bit of a mask built once).  conv_p1: dense 16x16 input (period 8); convT_s1: 14x14 input
+    under a 16x16 output (non-zero image-wrap constant on the input side); conv_p1_8x8: 8x8 maps (period 2, four image rows per
+    step).  The image counts give splits whose number of steps is not a multiple of the period, so the splits start at every phase
+    (the 3-image case of test_conv_family_fwd_dgrad_wgrad only ever starts at phase 0), and the last split is ragged.  Against the
+    oracle's shifted-matmul convolution, for the bf16 ping-pong kernel and -- same rounded inputs -- the exact-f32 2-stage kernel."""
     from theia_amd import ops
     dev = _dev()
     C, dt = 256, torch.bfloat16
-    IH = 16 if kind == "conv_p1" else 14
+    IH = {"conv_p1": 16, "convT_s1": 14, "conv_p1_8x8": 8}[kind]
     x = h((b, IH, IH, C), 31, 1.0)
     W = h((C, C, 3, 3), 32, 1.0 / math.sqrt(9 * C))
     xr, Wr = rnd(x, dt), rnd(W, dt)
     Wr.requires_grad_(True)
-    if kind == "conv_p1":
-        plan, ref = ops.plan_conv3x3(C, IH), O.conv3x3_p1(xr, Wr, torch.zeros(C))
-    else:
+    if kind == "convT_s1":
         plan, ref = ops.plan_convT3x3(C, IH, 1, 0, 0), O.convT3x3(xr, Wr, torch.zeros(C), 1, 0, 0)
-    assert ref.shape == (b, 16, 16, C) and not plan.wgrad_swapped
-    gy = h((b, 16, 16, C), 34, 1.0)
+    else:
+        plan, ref = ops.plan_conv3x3(C, IH), O.conv3x3_p1(xr, Wr, torch.zeros(C))
+    OH = plan.out_hw
+    assert ref.shape == (b, OH, OH, C) and not plan.wgrad_swapped and (OH * OH) % 32 == 0
+    gy = h((b, OH, OH, C), 34, 1.0)
     (ref * rnd(gy, dt)).sum().backward()
-    M = b * 256
+    M = b * OH * OH
     splits = ops.wgrad_splits(M, C, 9 * C)
-    assert splits == 28 and -(-(M // 32) // splits) % 8 != 0  # uneven: steps per split not a multiple of the period
+    steps_per_split, period = -(-(M // 32) // splits), OH * OH // 32
+    assert splits > 1 and steps_per_split % period != 0  # uneven: the splits do not start at phase 0
     for t in (dt, torch.float32):
         gw = torch.zeros(C, C, 3, 3, dtype=torch.float32, device=dev)
         ops.conv_wgrad(plan, rnd(gy, dt).to(dev, t).view(b, -1), xr.detach().to(dev, t).view(b, -1), b, C, gw, accumulate=False)

@@ -381,7 +381,8 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
     const bool modes = fast && allow_modes && !issue_in_m;
     const bool plain = modes && R_img == 1 && mp.ntaps == 1 && mp.dy[0] == 0 && mp.dx[0] == 0 && mp.in_h >= 1 && mp.in_w >= 1;
     // mode 2: no x wrap inside a step (the image width divides 32), whole steps per image, a period that fits the 32-bit mask
-    const bool periodic = modes && !plain && stages == 4 && R_img % 32 == 0 && R_img / 32 <= 32 && 32 % mp.rows_w == 0;
+    // (R_img == 32 is the whole-images case of the stepping path: its step constant already is the image stride)
+    const bool periodic = modes && !plain && stages == 4 && R_img % 32 == 0 && R_img >= 64 && R_img / 32 <= 32 && 32 % mp.rows_w == 0;
     if (plain && stages == 5) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 5, 1>), dim3(tiles * a->splits), dim3(512), lds5, stream, *a, plain_order);
     else if (plain) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 1>), dim3(tiles * a->splits), dim3(512), lds4, stream, *a, plain_order);
     else if (periodic) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 2>), dim3(tiles * a->splits), dim3(512), lds4, stream, *a, plain_order);
