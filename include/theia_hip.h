@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define THEIA_ABI_VERSION 6
+#define THEIA_ABI_VERSION 7
 
 enum { THEIA_OK = 0, THEIA_ERR_INVALID = -1, THEIA_ERR_LAUNCH = -2, THEIA_ERR_UNSUPPORTED = -3 };
 enum { THEIA_F32 = 0, THEIA_BF16 = 1,
@@ -174,6 +174,9 @@ typedef struct theia_wgrad_args {
 
 int theia_gemm_wgrad(const theia_wgrad_args_t* args, int dtype, void* stream);
 int theia_wgrad_fuses_bias(const theia_wgrad_args_t* args, int dtype);
+/* No launch: which kernel / row addressing a theia_gemm_wgrad call would use -- 0: the 2-stage kernel; the ping-pong kernel with
+ * 100: per-row decode, 110: stepped rows, 111: plain row-major matrices, 112: periodic rows (16x16-like images).  < 0: error. */
+int theia_gemm_wgrad_plan(const theia_wgrad_args_t* args, int dtype);
 /* recommended number of M-splits for (M, N, kslots*in_c) so that the launch fills the CU budget (theia_get_compute_cus) */
 int theia_wgrad_splits(int M, int N, int Ktot);
 

@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/theia_hip.h but not exported"
     assert sorted(N.EXPORTED_SYMBOLS) == declared, "ctypes signature table and header disagree"
-    assert lib.theia_abi_version() == N.ABI_VERSION == 6
+    assert lib.theia_abi_version() == N.ABI_VERSION == 7
     assert lib.theia_dtype_size(N.F32) == 4 and lib.theia_dtype_size(N.BF16) == 2 and lib.theia_dtype_size(7) == -1
 
 
@@ -112,6 +112,37 @@ def test_compute_cu_budget_steers_the_planners():
             ops.set_compute_cus(-1)
     finally:
         ops.set_compute_cus(0)
+
+
+def test_wgrad_row_mode_of_a_launch_is_host_logic():
+    """theia_gemm_wgrad_plan (no launch, no GPU): the 2-stage kernel for shapes the ping-pong kernel does not take, and for the ping-pong
+    kernel which row addressing -- plain matrices (every nn.Linear), periodic rows (16x16 output maps over a dense 16x16 or a 14x14
+    input, 8x8 maps), stepped rows (the stride-2 transposed convolutions, reduced over 31x31 / 16x16 input pixels with a non-dividing
+    width; images of exactly 32 pixels)."""
+    from theia_amd import _native as N, ops
+    lib = N.lib()
+    C, b = 768, 128
+
+    def plan(M, Nn, rmap, ldo, kslots=1, dtype=N.BF16):
+        g = N.WgradArgs()
+        g.M, g.N, g.ldo, g.kslots, g.splits = M, Nn, ldo, kslots, 1
+        g.map = rmap
+        return lib.theia_gemm_wgrad_plan(g, dtype)
+
+    assert plan(b * 197, C, ops.rm_plain(C, C, C), C) == 111 and plan(b * 197, 3 * C, ops.rm_plain(C, C, 3 * C), 3 * C) == 111
+    assert plan(b * 197, C, ops.rm_plain(C, C, C), C, dtype=N.F32) == 0          # exact-f32 mode: the 2-stage kernel
+    assert plan(b * 4096, 32, ops.rm_plain(C, C, 32), 32) == 0                   # N < 128
+    assert plan(b * 197, C, ops.rm_plain(192, 192, C), C) == 0                   # in_c not a multiple of 256
+    for p_, want in ((ops.plan_conv3x3(C, 16), 112), (ops.plan_convT3x3(C, 14, 1, 0, 0), 112), (ops.plan_conv3x3(C, 8), 112)):
+        assert not p_.wgrad_swapped
+        for rmap, mpi in p_.fwd:
+            assert plan(b * mpi, C, rmap, C, 9) == want, (want, mpi)
+    for p_ in (ops.plan_convT3x3(C, 16, 2, 1, 0), ops.plan_convT3x3(C, 31, 2, 0, 1)):  # reduced over input pixels: 256 (stride-2 gather) / 961
+        assert p_.wgrad_swapped
+        rmap, mpi = p_.dgrad
+        assert plan(b * mpi, C, rmap, C, 9) in (110, 112) and (mpi % 32 != 0) == (plan(b * mpi, C, rmap, C, 9) == 110)
+    small = ops.plan_conv3x3(C, 4)  # hypothetical 4x4 maps: 16 pixels per image -> two images per step: stepped rows
+    assert plan(b * 16, C, small.fwd[0][0], C, 9) == 110
 
 
 def test_every_bench_size_gemm_dispatches_the_pingpong_tile():

@@ -591,6 +591,7 @@ static int launch_wgrad(const theia_wgrad_args_t* a, hipStream_t stream) {
 
 int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream);  // gemm_wgrad_pp.hip
 bool theia_gemm_wgrad_pp_supported(const theia_wgrad_args_t* a);
+int theia_gemm_wgrad_pp_mode(const theia_wgrad_args_t* a);
 
 static bool wgrad_use_pp() {
     static int v = -1;
@@ -619,6 +620,12 @@ extern "C" int theia_wgrad_splits(int M, int N, int Ktot) {
     if (s > 64) s = 64;
     if (s < 1) s = 1;
     return s;
+}
+
+extern "C" int theia_gemm_wgrad_plan(const theia_wgrad_args_t* a, int dtype) {
+    if (a == nullptr) return THEIA_ERR_INVALID;
+    if (dtype == THEIA_BF16 && wgrad_use_pp() && theia_gemm_wgrad_pp_supported(a)) return 100 + theia_gemm_wgrad_pp_mode(a);
+    return 0;
 }
 
 extern "C" int theia_wgrad_fuses_bias(const theia_wgrad_args_t* a, int dtype) {

@@ -328,6 +328,39 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
 
 bool theia_gemm_wgrad_pp_supported(const theia_wgrad_args_t* a) { return a->map.in_c % 256 == 0 && a->N >= 128; }
 
+// Which row addressing the launch will use (host logic only; exported through theia_gemm_wgrad_plan): 0 = per-row decode (the maps
+// the stepping path cannot take), 10 = stepping (mode 0), 11 = plain matrices (mode 1), 12 = periodic (mode 2).  -1: not this kernel.
+int theia_gemm_wgrad_pp_mode(const theia_wgrad_args_t* a) {
+    if (!theia_gemm_wgrad_pp_supported(a)) return -1;
+    static int allow_fast = -1, allow_modes = -1, issue_in_m = -1, stages = -1;
+    if (allow_fast < 0) {
+        const char* e = getenv("THEIA_WGRAD_STEP");      // =general: A/B switch for the row-stepping fast path
+        allow_fast = (e != nullptr && strcmp(e, "general") == 0) ? 0 : 1;
+        e = getenv("THEIA_WGRAD_MODES");                 // =0: everything on mode 0
+        allow_modes = (e != nullptr && strcmp(e, "0") == 0) ? 0 : 1;
+        e = getenv("THEIA_WGRAD_ISSUE");                 // =m: both LDS-DMA rows in the M segment
+        issue_in_m = (e != nullptr && strcmp(e, "m") == 0) ? 1 : 0;
+        e = getenv("THEIA_WGRAD_STAGES");                // =5: 5-deep ring
+        stages = e != nullptr && atoi(e) == 5 ? 5 : 4;
+    }
+    const theia_rowmap_t& mp = a->map;
+    const int R_img = mp.rows_h * mp.rows_w;
+    // the stepping instantiation keeps its address steps (bytes) in 32 bits: one map row / one image of either operand below 1 GiB
+    const int64_t step_lim = (int64_t)1 << 29;  // elements
+    const bool steps_fit = (int64_t)mp.out_batch_stride * (R_img >= 32 ? 1 : 32 / (R_img > 0 ? R_img : 1)) < step_lim &&
+                           (int64_t)mp.in_batch_stride * (R_img >= 32 ? 1 : 32 / (R_img > 0 ? R_img : 1)) < step_lim &&
+                           (int64_t)mp.out_sy * mp.out_w * a->ldo * (mp.rows_h + 33) < step_lim &&
+                           (int64_t)mp.in_sy * mp.in_w * mp.in_c * (mp.rows_h + 33) < step_lim;
+    const bool fast = allow_fast && steps_fit && ((32 % R_img) == 0 || 32 / mp.rows_w + 1 <= mp.rows_h);
+    if (!fast) return 0;
+    const bool modes = allow_modes && !issue_in_m;
+    if (modes && R_img == 1 && mp.ntaps == 1 && mp.dy[0] == 0 && mp.dx[0] == 0 && mp.in_h >= 1 && mp.in_w >= 1) return 11;
+    // mode 2: no x wrap inside a step (the image width divides 32), whole steps per image, a period that fits the 32-bit mask
+    // (R_img == 32 is the whole-images case of the stepping path: its step constant already is the image stride)
+    if (modes && stages == 4 && R_img % 32 == 0 && R_img >= 64 && R_img / 32 <= 32 && 32 % mp.rows_w == 0) return 12;
+    return 10;
+}
+
 // bf16 only; requires in_c % 256 == 0.  Returns THEIA_ERR_UNSUPPORTED when the shape does not qualify.
 int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) {
     if (!theia_gemm_wgrad_pp_supported(a)) return THEIA_ERR_UNSUPPORTED;
@@ -349,19 +382,6 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
         stages = e != nullptr && atoi(e) == 5 ? 5 : 4;
     }
     const int tiles = cdiv_i(a->N, 256) * a->map.ntaps * (a->map.in_c / 256);
-    static int allow_fast = -1;  // THEIA_WGRAD_STEP=general: A/B switch for the row-stepping fast path
-    if (allow_fast < 0) {
-        const char* e = getenv("THEIA_WGRAD_STEP");
-        allow_fast = (e != nullptr && strcmp(e, "general") == 0) ? 0 : 1;
-    }
-    const int R_img = a->map.rows_h * a->map.rows_w;
-    // the stepping instantiation keeps its address steps (bytes) in 32 bits: one map row / one image of either operand below 1 GiB
-    const int64_t step_lim = (int64_t)1 << 29;  // elements
-    const bool steps_fit = (int64_t)a->map.out_batch_stride * (R_img >= 32 ? 1 : 32 / (R_img > 0 ? R_img : 1)) < step_lim &&
-                           (int64_t)a->map.in_batch_stride * (R_img >= 32 ? 1 : 32 / (R_img > 0 ? R_img : 1)) < step_lim &&
-                           (int64_t)a->map.out_sy * a->map.out_w * a->ldo * (a->map.rows_h + 33) < step_lim &&
-                           (int64_t)a->map.in_sy * a->map.in_w * a->map.in_c * (a->map.rows_h + 33) < step_lim;
-    const bool fast = allow_fast && steps_fit && ((32 % R_img) == 0 || 32 / a->map.rows_w + 1 <= a->map.rows_h);
     static int issue_in_m = -1;
     if (issue_in_m < 0) {
         const char* e = getenv("THEIA_WGRAD_ISSUE");
@@ -372,24 +392,15 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
         const char* e = getenv("THEIA_WGRAD_XCD");
         plain_order = (e != nullptr && strcmp(e, "0") == 0) ? 1 : 0;
     }
-    static int allow_modes = -1;
-    if (allow_modes < 0) {
-        const char* e = getenv("THEIA_WGRAD_MODES");
-        allow_modes = (e != nullptr && strcmp(e, "0") == 0) ? 0 : 1;
-    }
-    const theia_rowmap_t& mp = a->map;
-    const bool modes = fast && allow_modes && !issue_in_m;
-    const bool plain = modes && R_img == 1 && mp.ntaps == 1 && mp.dy[0] == 0 && mp.dx[0] == 0 && mp.in_h >= 1 && mp.in_w >= 1;
-    // mode 2: no x wrap inside a step (the image width divides 32), whole steps per image, a period that fits the 32-bit mask
-    // (R_img == 32 is the whole-images case of the stepping path: its step constant already is the image stride)
-    const bool periodic = modes && !plain && stages == 4 && R_img % 32 == 0 && R_img >= 64 && R_img / 32 <= 32 && 32 % mp.rows_w == 0;
-    if (plain && stages == 5) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 5, 1>), dim3(tiles * a->splits), dim3(512), lds5, stream, *a, plain_order);
-    else if (plain) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 1>), dim3(tiles * a->splits), dim3(512), lds4, stream, *a, plain_order);
-    else if (periodic) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 2>), dim3(tiles * a->splits), dim3(512), lds4, stream, *a, plain_order);
-    else if (fast && issue_in_m) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, false>), dim3(tiles * a->splits), dim3(512), lds4, stream, *a, plain_order);
-    else if (fast && stages == 5) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 5>), dim3(tiles * a->splits), dim3(512), lds5, stream, *a, plain_order);
-    else if (fast) hipLaunchKernelGGL(gemm_wgrad_pp_kernel<true>, dim3(tiles * a->splits), dim3(512), lds4, stream, *a, plain_order);
-    else hipLaunchKernelGGL(gemm_wgrad_pp_kernel<false>, dim3(tiles * a->splits), dim3(512), lds4, stream, *a, plain_order);
+    const int mode = theia_gemm_wgrad_pp_mode(a);
+    const dim3 grid(tiles * a->splits);
+    if (mode == 11 && stages == 5) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 5, 1>), grid, dim3(512), lds5, stream, *a, plain_order);
+    else if (mode == 11) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 1>), grid, dim3(512), lds4, stream, *a, plain_order);
+    else if (mode == 12) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 2>), grid, dim3(512), lds4, stream, *a, plain_order);
+    else if (mode == 10 && issue_in_m) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, false>), grid, dim3(512), lds4, stream, *a, plain_order);
+    else if (mode == 10 && stages == 5) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 5>), grid, dim3(512), lds5, stream, *a, plain_order);
+    else if (mode == 10) hipLaunchKernelGGL(gemm_wgrad_pp_kernel<true>, grid, dim3(512), lds4, stream, *a, plain_order);
+    else hipLaunchKernelGGL(gemm_wgrad_pp_kernel<false>, grid, dim3(512), lds4, stream, *a, plain_order);
     THEIA_CHECK_LAUNCH("theia_gemm_wgrad(pp)");
     if (a->bias_out != nullptr && a->defer_bias_reduce == 0) {
         hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv_i(a->N, 256)), dim3(256), 0, stream, a->bias_slabs, a->splits, a->N,
