@@ -294,7 +294,7 @@ def test_cu_reservation_during_backward_changes_the_schedule_not_the_result(monk
     finally:
         model.engine.bucket_ready_hook = None
         real(0)
-    assert calls == [full - 16, 0] and ops.get_compute_cus() == full, calls
+    assert calls == [full - 16, full] and ops.get_compute_cus() == full, calls  # restored to what it was, not to "0"
     for k in ("mse_loss", "cos_loss", "l1_loss"):
         assert float(la[k]) == float(lb[k])
     worst = 0.0

@@ -64,6 +64,41 @@ def test_probe_tr16_semantics():
             assert int(out[l, j]) == expect, (l, j, int(out[l, j]), expect)
 
 
+@pytest.mark.parametrize("tile", [0, 128128, 256256])
+def test_bf16_gelu_epilogue_over_a_wide_pre_activation_range(tile):
+    """The bf16 GELU epilogue evaluates Phi as a clamped polynomial (gemm_tile.h: gt_phi_sat).  Pre-activations swept over [-50, 50]
+    (an identity-like GEMM: x = the sweep in column block k, W = one-hot rows): the output must be EXACTLY 0 for x <= -4.5 (never a
+    small value of either sign), exactly bf16(x) for x >= 4.5, and within 2e-4 absolute of erf-GELU in between; the GELU-gradient
+    epilogue stays within [0 - 0.13, 1 + 0.13] (the exact derivative's range) and within 1e-3 of the exact derivative."""
+    from theia_amd import ops, _native as Nn
+    dev = _dev()
+    M, K, N = 4096, 64, 256
+    xs = torch.linspace(-50.0, 50.0, M).to(torch.bfloat16).float()
+    xs[:512] = torch.linspace(-6.0, 6.0, 512).to(torch.bfloat16).float()  # dense around the interesting part
+    x = torch.zeros(M, K)
+    x[:, 0] = xs
+    w = torch.zeros(N, K)
+    w[:, 0] = 1.0  # every output column = x[:, 0]
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    y = ops.linear(x.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), None, act=Nn.ACT_GELU, aux_out=pre, tile=tile).float().cpu()
+    assert torch.equal(pre.float().cpu(), xs[:, None].expand(M, N))
+    lo, hi = xs <= -4.5, xs >= 4.5
+    assert float(y[lo].abs().max()) == 0.0
+    assert torch.equal(y[hi], xs[hi, None].expand(-1, N))
+    ref = torch.nn.functional.gelu(xs.double())[:, None]
+    mid = ~(lo | hi)
+    assert float(((y[mid].double() - ref[mid]).abs() - ref[mid].abs() * 2 ** -8).max()) < 2e-4
+    ones = torch.zeros(M, K)
+    ones[:, 0] = 1.0
+    aux = xs[:, None].expand(M, N).contiguous()
+    g = ops.linear(ones.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), None, act=Nn.ACT_MUL_DGELU, aux_in=aux.to(dev, torch.bfloat16), tile=tile).float().cpu()
+    a64 = xs.double()
+    dg = (0.5 * (1 + torch.erf(a64 / math.sqrt(2))) + a64 * torch.exp(-0.5 * a64 * a64) / math.sqrt(2 * math.pi))[:, None]
+    assert float(g.min()) > -0.14 and float(g.max()) < 1.14
+    assert float(((g.double() - dg).abs() - dg.abs() * 2 ** -8).max()) < 1e-3
+    assert float(g[lo].abs().max()) < 1e-4 and float((g[hi] - 1.0).abs().max()) == 0.0  # (x * phi(x) = -7e-5 at -4.5: exact, not noise)
+
+
 # tile: 0 = the library's choice; 128128 / 256256 / 320256 = that kernel forced (256256 / 320256 are the persistent ping-pong kernel
 # with 256- / 320-row tiles that every bench-size GEMM runs on; theia_gemm_nt refuses the request instead of falling back, so a
 # passing forced case ran that kernel).  The f32 instantiation of the ping-pong kernel shares all of its indexing, zero-page,

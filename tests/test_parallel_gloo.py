@@ -136,9 +136,8 @@ def test_rccl_channel_cap_knob(monkeypatch):
     from theia_amd.parallel import DEFAULT_RCCL_CHANNELS, configure_rccl_env, rccl_channels, reserved_cus
     for v in ("NCCL_MAX_NCHANNELS", "THEIA_RCCL_MAX_NCHANNELS", "THEIA_DP_RESERVED_CUS"):
         monkeypatch.delenv(v, raising=False)
-    configure_rccl_env()  # default: a cap, and as many CUs left to RCCL while buckets are exchanged
-    assert os.environ["NCCL_MAX_NCHANNELS"] == str(DEFAULT_RCCL_CHANNELS) and reserved_cus() == DEFAULT_RCCL_CHANNELS
-    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    configure_rccl_env()  # default: opt-in -- RCCL's own channel choice, no CUs taken from the GEMM planners
+    assert DEFAULT_RCCL_CHANNELS == 0 and "NCCL_MAX_NCHANNELS" not in os.environ and reserved_cus() == 0
     monkeypatch.setenv("THEIA_RCCL_MAX_NCHANNELS", "8")
     configure_rccl_env()
     assert os.environ["NCCL_MAX_NCHANNELS"] == "8" and rccl_channels() == 8 and reserved_cus() == 8
@@ -163,3 +162,42 @@ def test_single_process_reducer_is_a_noop():
     r.bucket_ready(f)
     r.finish()
     assert r.world == 1 and torch.equal(f, torch.ones(16))
+
+
+def test_cu_budget_is_restored_to_what_it_was_not_to_the_whole_device():
+    """TheiaDataParallel shrinks the GEMM planners' CU budget while buckets are exchanged; afterwards -- and at the next forward() if a
+    backward pass raised before its completion callback -- the budget that was in force BEFORE comes back (a THEIA_COMPUTE_CUS the
+    user set survives), not "whole device"."""
+    from theia_amd import ops, parallel
+    calls = []
+    state = {"cus": 200}
+
+    class _Eng:
+        bucket_ready_hook = None
+
+    class _M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(4))
+            self.engine = _Eng()
+
+        def forward(self, x):
+            return x
+
+    orig = (ops.get_compute_cus, ops.set_compute_cus)
+    ops.get_compute_cus = lambda: state["cus"]
+    ops.set_compute_cus = lambda n: (calls.append(n), state.__setitem__("cus", n))
+    try:
+        ddp = parallel.TheiaDataParallel(_M(), broadcast=False)
+        ddp._reserve = 16
+        ddp._shrink_cus()
+        ddp._shrink_cus()  # idempotent: the saved budget is not overwritten by the reduced one
+        assert state["cus"] == 184 and ddp._saved_cus == 200
+        ddp._finalize()
+        assert state["cus"] == 200 and ddp._saved_cus is None
+        ddp._shrink_cus()
+        ddp._callback_queued = True  # a backward pass that raised: _finalize never ran
+        ddp(torch.zeros(1))
+        assert state["cus"] == 200 and not ddp._callback_queued
+    finally:
+        ops.get_compute_cus, ops.set_compute_cus = orig

@@ -114,14 +114,21 @@ __device__ __forceinline__ float gt_phi_poly(float x) {
     p = fmaf(p, s, 3.989298940e-01f);
     return fmaf(xc, p, 0.5f);
 }
+// Saturating form: the polynomial is within 1.25e-5 of Phi everywhere, so at the clamp (|x| >= 4.5, Phi = 3.4e-6 / 1 - 3.4e-6) it is
+// some constant in [-9e-6, 1.6e-5] (resp. 1 minus that) -- gelu(-50) would be -50 times that constant instead of 0.  Stretching by
+// (1 + 2 delta) around 1/2 with delta = 1.7e-5 and clamping to [0, 1] pins both tails to exactly 0 / 1 (gelu(x) = 0 for x <= -4.5, = x
+// for x >= 4.5) for two VALU operations; |error| <= 1.25e-5 + 1.7e-5 in between, still 1/100 of a bf16 ulp of Phi.
+__device__ __forceinline__ float gt_phi_sat(float x) {
+    return __builtin_amdgcn_fmed3f(fmaf(gt_phi_poly(x), 1.000034f, -1.7e-5f), 0.f, 1.f);
+}
 template <typename T> __device__ __forceinline__ float gt_gelu(float x) {
-    if constexpr (sizeof(T) == 2) return x * gt_phi_poly(x);
+    if constexpr (sizeof(T) == 2) return x * gt_phi_sat(x);
     else return gelu_erf(x);
 }
 template <typename T> __device__ __forceinline__ float gt_gelu_grad(float x) {
     if constexpr (sizeof(T) == 2) {  // Phi(x) + x * phi(x), phi = exp(-x^2 / 2) / sqrt(2 pi) through one v_exp_f32
         const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
-        return fmaf(x * e, 0.39894228040143267794f, gt_phi_poly(x));
+        return fmaf(x * e, 0.39894228040143267794f, gt_phi_sat(x));
     } else {
         return gelu_erf_grad(x);
     }

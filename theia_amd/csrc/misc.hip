@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(256) void grad_clip_coef_kernel(const float* __rest
         const float total = (float)sqrt(red[0]);
         out[0] = total;
         const float c = max_norm / (total + 1e-6f);
-        out[1] = c < 1.0f ? c : 1.0f;
+        out[1] = (c < 1.0f || c != c) ? c : 1.0f;  // a NaN norm propagates into every update, as torch's clip does
     }
 }
 extern "C" int theia_grad_clip_coef(const float* partials, int nparts, float max_norm, float* out2, void* stream) {

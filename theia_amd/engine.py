@@ -149,10 +149,28 @@ class Fp8Scales:
             return ops.quantize_fp8(x2d, sc, am, out=q), inv
         return ops.quantize_fp8(x2d, sc, am), inv
 
-    def update(self) -> None:
+    def update(self, activations_only: bool = False) -> None:
+        """amax -> next scale / inverse scale.  activations_only: leave the weight ("w:") slots alone -- their e4m3 copies in the
+        operand cache were quantised with the scale in force when the cache was built and carry a VIEW of this `inv`; refreshing a
+        weight slot without re-quantising the weight would rescale every output of that GEMM by amax_t / amax_{t-1}."""
         n = len(self.index)
-        if n:
+        if not n:
+            return
+        if not activations_only:
             ops.fp8_update_scales(self.amax[:n], self.scale[:n], self.inv[:n])
+            return
+        # slots are handed out in first-use order: maximal runs of consecutive activation slots, one launch each
+        names = sorted(self.index, key=self.index.get)
+        i = 0
+        while i < n:
+            if names[i].startswith("w:"):
+                i += 1
+                continue
+            j = i
+            while j < n and not names[j].startswith("w:"):
+                j += 1
+            ops.fp8_update_scales(self.amax[i:j], self.scale[i:j], self.inv[i:j])
+            i = j
 
 
 class _SideQueue:
@@ -442,7 +460,9 @@ class StudentEngine:
         """x [M, K] @ operand `key`^T with the epilogue `epi`: fp8 operands when the engine runs in fp8 mode and the operand has an
         e4m3 copy (K a multiple of 64, N >= 64), bf16 / f32 otherwise."""
         oc = self._opcache
-        if self.fp8 is not None and key + ".f8" in oc and "out" not in epi:
+        # (the fp8 operands exist for the persistent kernel only, which addresses M < 2^24 rows: beyond that -- a head's 64x64 maps at
+        # b >= 4096 per GPU -- the launch keeps its bf16 operands instead of failing in the middle of a step)
+        if self.fp8 is not None and key + ".f8" in oc and "out" not in epi and x.shape[0] < (1 << 24):
             x8, inv = self.fp8.quantize(x, "x:" + key)
             return ops.linear(x8, oc[key + ".f8"], bias, scale_inv=(inv, oc[key + ".inv"]), **epi)
         return ops.linear(x, oc[key], bias, **epi)
@@ -520,8 +540,9 @@ class StudentEngine:
             return _BackboneFn.apply(self, img, channels_last, do_rescale, do_normalize, geo, *params)
         if self.fp8 is not None:
             # delayed scaling outside training: the scales are otherwise refreshed only when the operand cache is rebuilt after an
-            # optimizer step, so an inference / eval loop would keep the activation scales of its first batch for ever
-            self.fp8.update()
+            # optimizer step, so an inference / eval loop would keep the activation scales of its first batch for ever.  Only the
+            # activation slots: a weight slot's scale belongs to the cached e4m3 copy of that weight
+            self.fp8.update(activations_only=True)
         z, _ = self._backbone_fwd(img, channels_last, do_rescale, do_normalize, save=False, geo=geo)
         return z
 
@@ -792,7 +813,7 @@ class StudentEngine:
         """(weight operand, None) -- or in fp8 mode (e4m3 weight, (inv_x, inv_w, e4m3 activation)): the activation (any NHWC /
         token layout with C channels innermost) is quantised as a [rows, C] matrix, the row map addresses it unchanged"""
         oc = self._opcache
-        if self.fp8 is not None and wkey + ".f8" in oc:
+        if self.fp8 is not None and wkey + ".f8" in oc and x.numel() // self.D < (1 << 22):  # (output rows <= 4x input rows < 2^24: see _mm)
             x8, inv = self.fp8.quantize(x.reshape(-1, self.D), "x:" + wkey)
             return oc[wkey + ".f8"], (inv, oc[wkey + ".inv"], x8)
         return oc[wkey], None

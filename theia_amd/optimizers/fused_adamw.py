@@ -46,6 +46,7 @@ class FusedAdamW(torch.optim.Optimizer):
         return self.param_groups[0]["lr"]
 
     def zero_grad(self, set_to_none: bool = True) -> None:
+        self._clip = None  # a coefficient computed for gradients that are being discarded must not reach a later step()
         for b in self.engine.buckets:
             for p in b.params:
                 if set_to_none:
@@ -90,7 +91,9 @@ class FusedAdamW(torch.optim.Optimizer):
         """``nn.utils.clip_grad_norm_`` (2-norm over every parameter with a gradient; train_rvfm.py:126-130) on the flat buckets, on
         the device: partial sums of squares per live range (fixed order), one finalize launch -> total norm and the factor
         min(1, max_norm / (norm + 1e-6)).  The NEXT ``step()`` multiplies every gradient with that factor inside the AdamW kernel; the
-        ``.grad`` tensors themselves stay unscaled (torch scales them in place).  Returns the total norm as a 0-d device tensor, like
+        ``.grad`` tensors themselves stay UNSCALED (torch scales them in place: code that reads ``.grad`` between this call and
+        ``step()`` sees unclipped values here); ``zero_grad()`` drops a coefficient that was not consumed; a NaN norm gives a NaN
+        coefficient (every updated parameter becomes NaN, as with torch).  Returns the total norm as a 0-d device tensor, like
         torch does -- reading it is the caller's host synchronisation, not this function's."""
         from .. import _native as N
         runs = list(self._live_runs())

@@ -19,12 +19,13 @@ import torch
 import torch.distributed as dist
 
 
-DEFAULT_RCCL_CHANNELS = 16
+DEFAULT_RCCL_CHANNELS = 0  # opt-in: no cap / no CU reservation until an 8-GPU A/B says otherwise (THEIA_RCCL_MAX_NCHANNELS=16 to try)
 
 
 def rccl_channels() -> int:
     """Channels (= workgroups, = CUs held for the length of a collective) RCCL may use: ``THEIA_RCCL_MAX_NCHANNELS`` (0 = leave RCCL's
-    own default, no CU reservation), else a ``NCCL_MAX_NCHANNELS`` the user exported, else ``DEFAULT_RCCL_CHANNELS``."""
+    own default, no CU reservation), else a ``NCCL_MAX_NCHANNELS`` the user exported, else ``DEFAULT_RCCL_CHANNELS`` (0: both the
+    channel cap and the CU reservation are OFF unless asked for -- neither has been measured at N > 1)."""
     n = os.environ.get("THEIA_RCCL_MAX_NCHANNELS")
     if n is not None and n != "":
         return max(0, int(n))
@@ -35,7 +36,8 @@ def rccl_channels() -> int:
 def configure_rccl_env() -> None:
     """Environment RCCL reads when the communicator is created -- call before ``init_process_group``.
 
-    Caps the number of channels RCCL runs a collective with (``NCCL_MAX_NCHANNELS`` = ``rccl_channels()``, 16 unless told otherwise).
+    Opt-in (``THEIA_RCCL_MAX_NCHANNELS=16``): caps the number of channels RCCL runs a collective with (``NCCL_MAX_NCHANNELS`` =
+    ``rccl_channels()``; default 0 = RCCL's own choice, nothing exported).
     The bucket all-reduces overlap the backward GEMMs; the persistent NT kernel and the weight-gradient kernel run one workgroup per
     CU with all of its registers and 130-150 KB of its LDS, so an RCCL workgroup cannot share a CU with them: every CU a collective
     holds pushes one workgroup of a 256-workgroup launch into a second round.  The two sides are therefore given disjoint CU sets:
@@ -204,15 +206,26 @@ class TheiaDataParallel(torch.nn.Module):
             broadcast_parameters(module.parameters(), 0, process_group)
         self._callback_queued = False
         self._reserve = 0
+        self._saved_cus: Optional[int] = None  # the budget in force before this wrapper shrank it (None: not shrunk)
         if self.reducer.world > 1:
             module.engine.bucket_ready_hook = self._on_bucket
             first = next(iter(module.parameters()), None)
             if first is not None and first.is_cuda and dist.get_backend(process_group) == "nccl":
                 self._reserve = reserved_cus()
 
-    def _set_cus(self, reserve: int) -> None:
+    def _shrink_cus(self) -> None:
+        """leave ``self._reserve`` CUs of the budget currently in force (the device, or a THEIA_COMPUTE_CUS the user set) to RCCL"""
         from . import ops
-        ops.set_compute_cus(0 if reserve == 0 else max(64, ops.device_cus() - reserve))
+        if self._saved_cus is None:
+            self._saved_cus = ops.get_compute_cus()
+            ops.set_compute_cus(max(64, self._saved_cus - self._reserve))
+
+    def _restore_cus(self) -> None:
+        """put back exactly the budget that was in force before ``_shrink_cus`` (not "whole device")"""
+        from . import ops
+        if self._saved_cus is not None:
+            ops.set_compute_cus(self._saved_cus)
+            self._saved_cus = None
 
     def _on_bucket(self, bucket, side_event=None) -> None:
         if not self._callback_queued:
@@ -220,14 +233,20 @@ class TheiaDataParallel(torch.nn.Module):
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
             self._callback_queued = True
             if self._reserve:
-                self._set_cus(self._reserve)  # launches enqueued from here on leave these CUs to the collectives
+                self._shrink_cus()  # launches enqueued from here on leave these CUs to the collectives
         self.reducer.bucket_ready(bucket.flat, side_event)
 
     def _finalize(self) -> None:
-        self.reducer.finish()
-        if self._reserve:
-            self._set_cus(0)
-        self._callback_queued = False
+        try:
+            self.reducer.finish()
+        finally:
+            self._restore_cus()
+            self._callback_queued = False
 
     def forward(self, *args, **kwargs):
+        # a backward pass that raised never reached _finalize: do not run the next step on the reduced budget / with stale state
+        self._restore_cus()
+        if self._callback_queued:
+            self._callback_queued = False
+            self.reducer._pending.clear()
         return self.module(*args, **kwargs)
