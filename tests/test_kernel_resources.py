@@ -52,13 +52,17 @@ def _steady_loops_are_scratch_free(text):
         for j in rd:
             if runs and j - runs[-1][1] < 40:
                 runs[-1][1] = j
+                runs[-1][2] += 1
             else:
-                runs.append([j, j])
-        loops = [r for r in runs if r[1] - r[0] >= 8]  # (the seamless path's 4 bias reads are a shorter run)
+                runs.append([j, j, 1])
+        loops = [r[:2] for r in runs if r[2] >= 8]  # (the seamless path's 4 bias reads are a shorter run, waited for on the spot)
         assert loops, (lines[st], runs)
         for lo, hi in loops:
             nxt = min(b for b in bar if b > hi)  # the barrier that opens the M segment
-            assert not any("scratch_" in body[j] for j in range(lo, nxt)), (lines[st], lo, nxt)
+            # ... and none in the 60 instructions in front of the first read either: a reload of the fragment address registers there is
+            # followed by a compiler-inserted vmcnt(0) that drains the operand prefetch once per half-tile (round 4: an epilogue change
+            # made the 320-row instantiations do exactly that, every 320-row shape 30-40 % slower with all parity tests green)
+            assert not any("scratch_" in body[j] for j in range(max(0, lo - 60), nxt)), (lines[st], lo, nxt)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")

@@ -7,6 +7,21 @@
 #include <vector>
 #include <string>
 #include "../theia_amd/csrc/gemm_pp.hip"
+#ifdef WITH_DW  // the dual-workgroup experiment (tools/experiments/gemm_dw.hip): not kept, not in the library
+#include "experiments/gemm_dw.hip"
+#endif
+
+// tile request -> kernel: 256256 / 320256 = the 8-wave ping-pong kernel, 128256 / 160256 = the dual-workgroup kernel
+static int launch_any(const theia_gemm_args_t* g, hipStream_t s) {
+#ifdef WITH_DW
+    if (g->tile == 128256 || g->tile == 160256) return theia_gemm_nt_dw_launch(g, THEIA_BF16, s);
+#endif
+    return theia_gemm_nt_pp_launch(g, THEIA_BF16, s);
+}
+#ifndef WITH_DW
+static int g_dw_grid_cap = 0;
+static int theia_gemm_nt_dw_bm(const theia_gemm_args_t*, int) { return 0; }
+#endif
 
 int theia_compute_cus() {  // (misc.hip in the library)
     int v = 0;
@@ -70,7 +85,7 @@ static int check_one(const Bufs& b, int M, int N, int K, int act, bool bias, boo
     theia_gemm_args_t g = make_args(b, M, N, K, act, bias, resid, tile);
     hipMemset(b.o, 0xff, (size_t)M * N * 2);
     hipMemset(b.aux_out, 0xff, (size_t)M * N * 2);
-    int rc = theia_gemm_nt_pp_launch(&g, THEIA_BF16, 0);
+    int rc = launch_any(&g, 0);
     if (rc) { printf("launch rc=%d\n", rc); return 1; }
     ref_gemm<<<dim3((N + 255) / 256, M), 256>>>(b.a, b.w, bias ? b.bias : nullptr, resid ? b.res : nullptr, g.aux_in ? b.aux_in : nullptr,
                                                  b.ref, b.ref_pre, M, N, K, act);
@@ -105,11 +120,11 @@ static int check_one(const Bufs& b, int M, int N, int K, int act, bool bias, boo
 
 static double time_one(const Bufs& b, int M, int N, int K, int act, bool bias, bool resid, int tile, int iters) {
     theia_gemm_args_t g = make_args(b, M, N, K, act, bias, resid, tile);
-    for (int it = 0; it < 3; ++it) theia_gemm_nt_pp_launch(&g, THEIA_BF16, 0);
+    for (int it = 0; it < 3; ++it) launch_any(&g, 0);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
-    for (int it = 0; it < iters; ++it) theia_gemm_nt_pp_launch(&g, THEIA_BF16, 0);
+    for (int it = 0; it < iters; ++it) launch_any(&g, 0);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     return ms * 1000.0 / iters;
@@ -128,12 +143,19 @@ int main(int argc, char** argv) {
     { std::vector<float> hb(4096); for (auto& v : hb) v = frand(); hipMemcpy(b.bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice); }
     int fails = 0;
     if (what == "check" || what == "all") {
-        int tiles[2] = {256256, 320256};
+        int tiles[4] = {256256, 320256, 128256, 160256};
         if (getenv("PPB_ONLY320")) tiles[0] = 320256;
+        const int t_lo = getenv("PPB_ONLY_DW") ? 2 : 0;
+#ifdef WITH_DW
+        const int t_hi = 4;
+#else
+        const int t_hi = 2;
+#endif
         for (int cap = 0; cap <= 5; cap += 5) {  // cap 5: every workgroup walks over several tiles, the last round is partial
             g_pp_grid_cap = cap;
+            g_dw_grid_cap = cap;
             printf("-- persistent grid cap %d\n", cap);
-            for (int ti = 0; ti < 2; ++ti) {
+            for (int ti = t_lo; ti < t_hi; ++ti) {
                 const int t = tiles[ti];
                 fails += check_one(b, 1000, 768, 768, THEIA_ACT_NONE, false, false, t);
                 fails += check_one(b, 1000, 768, 768, THEIA_ACT_NONE, true, false, t);
@@ -148,6 +170,7 @@ int main(int argc, char** argv) {
             }
         }
         g_pp_grid_cap = 0;
+        g_dw_grid_cap = 0;
         printf("%d failures\n", fails);
     }
     if (what == "time" || what == "all") {
@@ -162,12 +185,53 @@ int main(int argc, char** argv) {
         for (const S& s : shapes) {
             const double t256 = time_one(b, s.M, s.N, s.K, s.act, s.bias, s.resid, 256256, iters);
             const double t320 = time_one(b, s.M, s.N, s.K, s.act, s.bias, s.resid, 320256, iters);
+#ifdef WITH_DW
+            const double t128 = time_one(b, s.M, s.N, s.K, s.act, s.bias, s.resid, 128256, iters);
+            const double t160 = time_one(b, s.M, s.N, s.K, s.act, s.bias, s.resid, 160256, iters);
+#else
+            const double t128 = 1e30, t160 = 1e30;
+#endif
             const double fl = 2.0 * s.M * s.N * s.K;
             theia_gemm_args_t g = make_args(b, s.M, s.N, s.K, s.act, s.bias, s.resid, 0);
-            printf("%s M=%6d N=%4d K=%4d: BM256 %7.1f us %7.1f TF | BM320 %7.1f us %7.1f TF | auto -> %d\n", s.name, s.M, s.N, s.K, t256,
-                   fl / t256 / 1e6, t320, fl / t320 / 1e6, theia_gemm_nt_pp_bm(&g, THEIA_BF16));
+            printf("%s M=%6d N=%4d K=%4d: BM256 %7.1f us %7.1f TF | BM320 %7.1f us %7.1f TF | auto -> %d || dw128 %7.1f us %7.1f TF | dw160 %7.1f us %7.1f TF | auto -> %d\n",
+                   s.name, s.M, s.N, s.K, t256, fl / t256 / 1e6, t320, fl / t320 / 1e6, theia_gemm_nt_pp_bm(&g, THEIA_BF16), t128, fl / t128 / 1e6, t160,
+                   fl / t160 / 1e6, theia_gemm_nt_dw_bm(&g, THEIA_BF16));
         }
     }
+#if defined(PP_TRACE) && defined(WITH_DW)
+    {
+        struct S { const char* name; int M, N, K, act; bool bias, resid; int tile; };
+        const S dcfg[] = {{"fc1 gelu dw128", 25216, 3072, 768, THEIA_ACT_GELU, true, false, 128256},
+                          {"fc1 gelu dw160", 25216, 3072, 768, THEIA_ACT_GELU, true, false, 160256},
+                          {"qkv none dw160", 25216, 2304, 768, THEIA_ACT_NONE, true, false, 160256},
+                          {"fc2_d dgelu dw128", 25216, 3072, 768, THEIA_ACT_MUL_DGELU, false, false, 128256},
+                          {"fc2 resid dw160", 25216, 768, 3072, THEIA_ACT_NONE, true, true, 160256},
+                          {"proj_d none dw160", 25216, 768, 768, THEIA_ACT_NONE, false, false, 160256}};
+        for (const S& c : dcfg) {
+            theia_gemm_args_t g = make_args(b, c.M, c.N, c.K, c.act, c.bias, c.resid, c.tile);
+            for (int rep = 0; rep < 4; ++rep) launch_any(&g, 0);
+            hipDeviceSynchronize();
+            unsigned long long ph[8][16];
+            unsigned int ids[512][2];
+            hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_dw_phase), sizeof(ph));
+            hipMemcpyFromSymbol(ids, HIP_SYMBOL(g_dw_ids), sizeof(ids));
+            printf("%s: block 0 stamps (entry, addr set-up, prologue issued, then per tile: loop start, loop end, epilogue end, next tile ready)\n", c.name);
+            for (int wv = 0; wv < 4; wv += 3) {
+                printf("  wave %d:", wv);
+                for (int k = 0; k < 16; ++k) printf(" %7lld", (long long)(ph[wv][k] - ph[0][0]));
+                printf("\n");
+            }
+            if (&c == &dcfg[0]) {
+                printf("  HW_ID / LDS_ALLOC of blocks 0..15, 256..271:");
+                for (int k = 0; k < 16; ++k) printf(" %08x/%08x", ids[k][0], ids[k][1]);
+                for (int k = 256; k < 272; ++k) printf(" %08x/%08x", ids[k][0], ids[k][1]);
+                printf("\n");
+                int lead = 0; for (int k = 0; k < 512; ++k) lead += (ids[k][1] & 0xfff) == 0;
+                printf("  blocks with LDS base 0: %d of 512\n", lead);
+            }
+        }
+    }
+#endif
 #ifdef PP_TRACE
     {
         struct S { const char* name; int M, N, K, act; bool bias, resid; int tile; };
@@ -179,7 +243,7 @@ int main(int argc, char** argv) {
                          {"proj resid BM256", 25216, 768, 768, THEIA_ACT_NONE, true, true, 256256}};
         for (const S& c : cfg) {
             theia_gemm_args_t g = make_args(b, c.M, c.N, c.K, c.act, c.bias, c.resid, c.tile);
-            for (int rep = 0; rep < 4; ++rep) theia_gemm_nt_pp_launch(&g, THEIA_BF16, 0);  // back to back: the stamps are the last launch's
+            for (int rep = 0; rep < 4; ++rep) launch_any(&g, 0);  // back to back: the stamps are the last launch's
             hipDeviceSynchronize();
             unsigned long long ph[8][16];
             hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_pp_phase), sizeof(ph));
