@@ -452,11 +452,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         PP_PHASE(4 + 4 * r)
         {
             const gd_rows_t rw(p);
-            // (the 320-row instantiations keep the accumulator lane order for their rows for now: with the lane transposes in the epilogue the
-            // register allocator -- all 256 registers in use -- reloaded the fragment address registers inside the main loop, two vmcnt(0)
-            // per half-tile: every 320-row shape 30-40 % slower, profiles/r04_epilogue_lane_order.txt)
-            constexpr bool ROWMAJOR = BM != 320;
-            const int it0 = gd_epilogue<OutT, FM, SUMS, SCALE, BIAS_IN_ACC, ROWMAJOR>(acc, p, rw, m0 + wm * WM, n0 + wn * WN, threadIdx.x & 63, resid_init, sums_tab, m0);
+            const int it0 = gd_epilogue<OutT, FM, SUMS, SCALE, BIAS_IN_ACC>(acc, p, rw, m0 + wm * WM, n0 + wn * WN, threadIdx.x & 63, resid_init, sums_tab, m0);
             if constexpr (SUMS) flush_img0 = it0;
         }
         PP_PHASE(5 + 4 * r)

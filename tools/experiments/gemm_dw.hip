@@ -35,7 +35,7 @@
 //   Tile boundary: the epilogue's stores stay in flight into the next loop; loads retire in order among loads, so a counted wait is only
 //   made stricter by them (see gemm_pp.hip).  The next tile's first two half-tiles were requested by the last two iterations.
 #include <type_traits>
-#include "../../theia_amd/csrc/gemm_epi_direct.h"
+#include "../../theia_amd/csrc/gemm_epi_direct.h"  // (the library's epilogue: accumulator lane order)
 
 __device__ uint4 g_dw_zero_page[1024 + 1];
 

@@ -1,3 +1,7 @@
+// EXPERIMENT, NOT PART OF THE LIBRARY (round 4, measured and not kept: profiles/r04_epilogue_lane_order.txt).  gemm_epi_direct.h with the
+// bf16 rows of the epilogue stored / loaded in a row-major lane order (ds_bpermute lane transposes so that the 4 lanes of a quad touch 64
+// contiguous bytes: 4x the per-CU store rate in tools/store_bench.hip).  Isolated: -3...-6 % on the 256-row shapes whose epilogue is not
+// VALU-bound, nothing on the 320-row ones; whole step (base b=128, small b=256, tiny b=256, three libraries alternating on one box): no gain.
 // LDS-free epilogue of the ping-pong GEMM kernels: the accumulators are converted and stored straight from the MFMA layout.
 //
 // gt_epilogue (gemm_tile.h) stages every wave tile through LDS to get 16-byte row-contiguous stores: two staging passes (~1.8k
@@ -113,7 +117,55 @@ template <typename T> struct gd_ctx_t {
     int64_t off_dead;
     int m_split;
     float ls0, lq0, ls1, lq1;
+    int n_wave0, N;  // (wave-uniform) first column of the wave tile, columns of the matrix: the row-major lane order derives its columns from them
 };
+
+// Row traffic with ADJACENT lanes on adjacent bytes.  In the accumulator layout lane l = frow + 16 * fg holds the 16-byte piece fg of row
+// frow: consecutive lanes are consecutive ROWS, the four pieces of a row's 64 bytes sit in lanes 16 apart.  The vector memory path
+// coalesces only within a quad of adjacent lanes: such an instruction becomes 64 separate 16-byte requests and runs at ~14 B/clk per CU
+// -- alone on the chip as well as with all 256 CUs storing (tools/store_bench.hip, profiles/r04_store_path_microbench.txt: 128 KB from ONE
+// CU takes 9.3 k cycles in this lane order, 2.5 k with the same 16 rows x 64 bytes per instruction but lanes 4r..4r+3 on row r; and the
+// GEMM epilogues took the same 15-22 k cycles per fc1 tile with 64, 128 or 256 CUs running, profiles/r04_epilogue_vs_grid.txt).  Round 3
+// read those 14 B/clk x 256 CUs as "the HBM write rate of a chip-wide burst"; it is the per-CU price of the lane order.
+// So the packed pieces change lanes before they are stored (and after they are loaded): lane L of the row-major order owns row L >> 2,
+// piece L & 3 -- one ds_bpermute_b32 per dword (the LDS crossbar, no LDS memory), 8 per 16-row fragment pair.
+// (the source-lane addresses are recomputed from an opaque read of the thread index at every use -- 4 VALU operations -- instead of
+// living in registers across the epilogue: the row-prefetch epilogues run at 256 registers, and a spilled register with an
+// inline-asm load in flight is garbage)
+__device__ __forceinline__ int gd_lane_now() {  // (v_mbcnt: no dependence on the thread-index register either)
+    int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+}
+__device__ __forceinline__ void gd_to_rows(gt_u32x4& p) {  // accumulator lane order -> row-major lane order: from lane (L >> 2) + 16 * (L & 3)
+    const int l = gd_lane_now();
+    const int a = ((l >> 2) | ((l & 3) << 4)) << 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p[e] = (unsigned)__builtin_amdgcn_ds_bpermute(a, (int)p[e]);
+}
+__device__ __forceinline__ void gd_from_rows(gt_u32x4& p) {  // row-major lane order -> accumulator lane order: from lane 4 * frow + fg
+    const int l = gd_lane_now();
+    const int a = (((l & 15) << 2) | (l >> 4)) << 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p[e] = (unsigned)__builtin_amdgcn_ds_bpermute(a, (int)p[e]);
+}
+// column of this lane's 16-byte piece of column half t in the row-major lane order (recomputed at every use, like the lane addresses)
+__device__ __forceinline__ int gd_scol(int n_wave0, int t) { return n_wave0 + t * 32 + (gd_lane_now() & 3) * 8; }
+__device__ __forceinline__ gt_u32x4 gd_pack8(const float (&v)[8]) {
+    return (gt_u32x4){pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
+}
+// the two 16-byte stores of a 16-row fragment's packed pieces (accumulator lane order in, `sc` = cursor of the lane's row in the
+// row-major order)
+template <typename T>
+__device__ __forceinline__ void gd_store_pair(gt_u32x4 p0, gt_u32x4 p1, T* base, const gd_rows_t::cursor_t& sc, const gd_ctx_t<T>& cx, int M) {
+    gd_to_rows(p0);
+    gd_to_rows(p1);
+    const bool lm = sc.m < M;
+    T* const dump = reinterpret_cast<T*>(g_gt_dump) + gd_lane_now() * 8;
+    const int c0 = gd_scol(cx.n_wave0, 0);
+    *reinterpret_cast<gt_u32x4*>(lm && c0 < cx.N ? base + sc.off + c0 : dump) = p0;
+    *reinterpret_cast<gt_u32x4*>(lm && c0 + 32 < cx.N ? base + sc.off + c0 + 32 : dump) = p1;
+}
 
 template <int N> __device__ __forceinline__ void gd_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -160,22 +212,26 @@ __device__ __forceinline__ void gd_apply(const gt_f32x4 (&acc)[4][FM], int j, in
 //   C  all stores.
 // Loads and stores share the vmcnt counter and retire out of order with respect to each other, so a wait between stores is always a
 // wait for everything (the first version of this epilogue prefetched chunk c+1 around chunk c's stores and waited vmcnt(0) per chunk).
-template <typename T, int FM, bool SUMS, bool SCALE, bool BIAS_IN_ACC, int ACT, bool PRE>
+template <typename T, int FM, bool SUMS, bool SCALE, bool BIAS_IN_ACC, int ACT, bool PRE, bool ROWMAJOR>
 __device__ __forceinline__ void gd_epilogue_body(gt_f32x4 (&acc)[4][FM], const theia_gemm_args_t& p, const gd_rows_t& rw, int m_row0,
                                                  gd_ctx_t<T>& cx) {
     constexpr bool WANT_AUX = ACT == THEIA_ACT_MUL_DGELU || ACT == THEIA_ACT_MUL_DRELU;
-    gd_rows_t::cursor_t cur = rw.first(p, m_row0);
+    constexpr bool RM = ROWMAJOR && sizeof(T) == 2;
+    static_assert(!PRE || RM, "the row prefetch uses the row-major lane order");
+    // bf16 rows are read and written in the row-major lane order (see gd_to_rows): this lane's first row there
+    const int m_srow0 = m_row0 - (gd_lane_now() & 15) + (gd_lane_now() >> 2);
     if constexpr (PRE) {
         static_assert(sizeof(T) == 2 && !SUMS, "row prefetch: bf16 outputs, no statistics");
         const T* __restrict__ PREP = WANT_AUX ? cx.AUXI : cx.RES;
         gt_u32x4 rows[FM][2];
-        gd_rows_t::cursor_t pc = cur;
+        gd_rows_t::cursor_t pc = rw.first(p, m_srow0);  // (dead after phase A; phase C decodes its own: no cursor is alive in phase B)
 #pragma unroll
         for (int j = 0; j < FM; ++j) {  // phase A; dead lanes read row 0 (valid memory)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const bool lv = (pc.m < p.M) && cx.nok[t];
-                gd_load16(rows[j][t], PREP + (lv ? pc.off + cx.ncol[t] : cx.off_dead));
+                const int c = gd_scol(cx.n_wave0, t);
+                const bool lv = (pc.m < p.M) && c < cx.N;
+                gd_load16(rows[j][t], PREP + (lv ? pc.off + c : cx.off_dead));
             }
             rw.next(pc);
         }
@@ -185,39 +241,60 @@ __device__ __forceinline__ void gd_epilogue_body(gt_f32x4 (&acc)[4][FM], const t
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 asm volatile("" : "+v"(rows[j][t]));
+                gd_from_rows(rows[j][t]);
                 float a8[8], v[8], pre[8];
                 gd_unpack8(rows[j][t], a8);
                 gd_apply<T, FM, SCALE, BIAS_IN_ACC, ACT>(acc, j, t, cx, a8, !WANT_AUX, a8, v, pre);
-                rows[j][t] = (gt_u32x4){pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
+                rows[j][t] = gd_pack8(v);
             }
         });
+        gd_rows_t::cursor_t sc = rw.first(p, m_srow0);
 #pragma unroll
         for (int j = 0; j < FM; ++j) {  // phase C
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const bool live = (cur.m < p.M) && cx.nok[t];
-                T* dst = live ? cx.O + cur.off + cx.ncol[t] : cx.dump;
-                *reinterpret_cast<gt_u32x4*>(dst) = rows[j][t];
-            }
-            rw.next(cur);
+            gd_store_pair<T>(rows[j][0], rows[j][1], cx.O, sc, cx, p.M);
+            rw.next(sc);
         }
         return;
     }
+    gd_rows_t::cursor_t cur = rw.first(p, m_row0);
+    [[maybe_unused]] gd_rows_t::cursor_t sc = rw.first(p, m_srow0);
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
+        [[maybe_unused]] gt_u32x4 pk[2], pkpre[2];  // bf16 outputs: the packed pieces of the two column halves (stored after the loop over t)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const bool live = (cur.m < p.M) && cx.nok[t];
             const int64_t o = live ? cur.off + cx.ncol[t] : cx.off_dead;
             float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v[8], pre[8];
-            if constexpr (WANT_AUX) load8(cx.AUXI + o, a8);
             const bool has_res = ACT == THEIA_ACT_NONE && cx.RES != nullptr;
-            if (has_res) load8(cx.RES + o, r8);
-            gd_apply<T, FM, SCALE, BIAS_IN_ACC, ACT>(acc, j, t, cx, a8, has_res, r8, v, pre);
-            if constexpr (ACT == THEIA_ACT_GELU) {
-                if (cx.AUXO != nullptr) store8(live ? cx.AUXO + o : cx.dump, pre);
+            if constexpr (RM) {  // rows arrive in the row-major lane order and change lanes
+                const int c = gd_scol(cx.n_wave0, t);
+                const bool slive = (sc.m < p.M) && c < cx.N;
+                const int64_t so = slive ? sc.off + c : cx.off_dead;
+                if constexpr (WANT_AUX) {
+                    gt_u32x4 raw = *reinterpret_cast<const gt_u32x4*>(cx.AUXI + so);
+                    gd_from_rows(raw);
+                    gd_unpack8(raw, a8);
+                }
+                if (has_res) {
+                    gt_u32x4 raw = *reinterpret_cast<const gt_u32x4*>(cx.RES + so);
+                    gd_from_rows(raw);
+                    gd_unpack8(raw, r8);
+                }
+            } else {
+                if constexpr (WANT_AUX) load8(cx.AUXI + o, a8);
+                if (has_res) load8(cx.RES + o, r8);
             }
-            store8(live ? cx.O + o : cx.dump, v);
+            gd_apply<T, FM, SCALE, BIAS_IN_ACC, ACT>(acc, j, t, cx, a8, has_res, r8, v, pre);
+            if constexpr (RM) {
+                pk[t] = gd_pack8(v);
+                if constexpr (ACT == THEIA_ACT_GELU) pkpre[t] = gd_pack8(pre);
+            } else {
+                if constexpr (ACT == THEIA_ACT_GELU) {
+                    if (cx.AUXO != nullptr) store8(live ? cx.AUXO + o : cx.dump, pre);
+                }
+                store8(live ? cx.O + o : cx.dump, v);
+            }
             if constexpr (SUMS) {
                 float s = 0.f, sq = 0.f;
 #pragma unroll
@@ -238,6 +315,13 @@ __device__ __forceinline__ void gd_epilogue_body(gt_f32x4 (&acc)[4][FM], const t
                 asm volatile("" : "+v"(cx.ls0), "+v"(cx.lq0), "+v"(cx.ls1), "+v"(cx.lq1));
             }
         }
+        if constexpr (RM) {
+            if constexpr (ACT == THEIA_ACT_GELU) {
+                if (cx.AUXO != nullptr) gd_store_pair<T>(pkpre[0], pkpre[1], cx.AUXO, sc, cx, p.M);
+            }
+            gd_store_pair<T>(pk[0], pk[1], cx.O, sc, cx, p.M);
+            rw.next(sc);
+        }
         rw.next(cur);
     }
 }
@@ -245,10 +329,14 @@ __device__ __forceinline__ void gd_epilogue_body(gt_f32x4 (&acc)[4][FM], const t
 // acc: FM x 4 fragments of one wave (rows m_wave0 .. +16*FM, columns n_wave0 .. +64 in the permuted order above).
 // T = output element type.  BIAS_IN_ACC: the kernel initialised the accumulators with the bias row (then it is not added again);
 // resid_in_acc: the same for the residual rows (act == NONE only).  SCALE: fp8 operands, accumulators are rescaled first.
-template <typename T, int FM, bool SUMS, bool SCALE, bool BIAS_IN_ACC>
+// ROWMAJOR = false: bf16 rows in the accumulator lane order as in round 3 (one instantiation of gemm_pp.hip keeps it: see there)
+template <typename T, int FM, bool SUMS, bool SCALE, bool BIAS_IN_ACC, bool ROWMAJOR = true>
 __device__ __forceinline__ int gd_epilogue(gt_f32x4 (&acc)[4][FM], const theia_gemm_args_t& p, const gd_rows_t& rw, int m_wave0,
                                            int n_wave0, int lane, bool resid_in_acc, unsigned long long* sums_tab = nullptr,
                                            int m_tile0 = 0) {  // -> SUMS: the tile's first image (for gt_flush_sums), else 0
+    // every lane constant of the epilogue is derived from an OPAQUE copy of the lane index: hoisted out of the caller's tile loop they
+    // would be registers alive across its main loop, which has none to spare (a 320-row build spilled inside a fragment-read window)
+    asm volatile("" : "+v"(lane));
     const int frow = lane & 15, fg = lane >> 4;
     gd_ctx_t<T> cx;
     cx.O = reinterpret_cast<T*>(p.out);
@@ -270,6 +358,8 @@ __device__ __forceinline__ int gd_epilogue(gt_f32x4 (&acc)[4][FM], const theia_g
     int dry, drx;
     cx.off_dead = rw.decode(p, 0, dry, drx);  // where dead lanes (rows >= M, columns >= N) read from: row 0, column 0
     cx.dump = reinterpret_cast<T*>(g_gt_dump) + lane * 8;
+    cx.n_wave0 = n_wave0;
+    cx.N = p.N;
     // per-image (sum, sum of squares) of the stored values: see gt_epilogue
     unsigned long long* const lsum = SUMS ? reinterpret_cast<unsigned long long*>(p.ln_sums) : nullptr;
     int img0 = 0, img_tile0 = 0;
@@ -286,17 +376,17 @@ __device__ __forceinline__ int gd_epilogue(gt_f32x4 (&acc)[4][FM], const theia_g
     constexpr bool CAN_PRE = sizeof(T) == 2 && FM <= 8 && !SUMS && BIAS_IN_ACC;  // (fp8 operands: 16 bias registers more, no room)
     const int m_row0 = m_wave0 + frow;
     if constexpr (SUMS) {  // the statistics launches are the convolutions in front of a LayerNorm[C,H,W]: no activation or ReLU
-        if (p.act == THEIA_ACT_RELU) gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_RELU, false>(acc, p, rw, m_row0, cx);
-        else gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_NONE, false>(acc, p, rw, m_row0, cx);
+        if (p.act == THEIA_ACT_RELU) gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_RELU, false, ROWMAJOR>(acc, p, rw, m_row0, cx);
+        else gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_NONE, false, ROWMAJOR>(acc, p, rw, m_row0, cx);
     } else {
         switch (p.act) {
-            case THEIA_ACT_GELU: gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_GELU, false>(acc, p, rw, m_row0, cx); break;
-            case THEIA_ACT_RELU: gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_RELU, false>(acc, p, rw, m_row0, cx); break;
-            case THEIA_ACT_MUL_DGELU: gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_MUL_DGELU, CAN_PRE>(acc, p, rw, m_row0, cx); break;
-            case THEIA_ACT_MUL_DRELU: gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_MUL_DRELU, CAN_PRE>(acc, p, rw, m_row0, cx); break;
+            case THEIA_ACT_GELU: gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_GELU, false, ROWMAJOR>(acc, p, rw, m_row0, cx); break;
+            case THEIA_ACT_RELU: gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_RELU, false, ROWMAJOR>(acc, p, rw, m_row0, cx); break;
+            case THEIA_ACT_MUL_DGELU: gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_MUL_DGELU, (CAN_PRE) && ROWMAJOR, ROWMAJOR>(acc, p, rw, m_row0, cx); break;
+            case THEIA_ACT_MUL_DRELU: gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_MUL_DRELU, (CAN_PRE) && ROWMAJOR, ROWMAJOR>(acc, p, rw, m_row0, cx); break;
             default:
-                if (CAN_PRE && cx.RES != nullptr) gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_NONE, CAN_PRE>(acc, p, rw, m_row0, cx);
-                else gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_NONE, false>(acc, p, rw, m_row0, cx);
+                if (CAN_PRE && cx.RES != nullptr) gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_NONE, (CAN_PRE) && ROWMAJOR, ROWMAJOR>(acc, p, rw, m_row0, cx);
+                else gd_epilogue_body<T, FM, SUMS, SCALE, BIAS_IN_ACC, THEIA_ACT_NONE, false, ROWMAJOR>(acc, p, rw, m_row0, cx);
                 break;
         }
     }
