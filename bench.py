@@ -87,6 +87,8 @@ def parse(argv=None):
     ap.add_argument("--stream-batch", type=int, default=4096, help="forward_feature: images streamed per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="single GPU: run the step as ONE hipGraph replay (theia_amd/train_graph.py) instead of ~1500 eager launches")
     ap.add_argument("--no-selfcheck", action="store_true", help="tuning runs only: the printed line is marked unchecked")
     ap.add_argument("--no-optimizer", action="store_true", help="exclude the AdamW update from the step")
     return ap.parse_args(argv)
@@ -290,7 +292,8 @@ def src_sha(files):
     return h.hexdigest()[:16]
 
 
-NT_KERNEL_SOURCES = ["theia_amd/csrc/gemm_pp.hip", "theia_amd/csrc/gemm_epi_direct.h", "theia_amd/csrc/gemm_tile.h", "theia_amd/csrc/gemm.hip"]
+# the sources of the persistent NT kernel itself (not gemm.hip: host dispatch + the 2-stage kernel -- an edit there voided round 3's summary)
+NT_KERNEL_SOURCES = ["theia_amd/csrc/gemm_pp.hip", "theia_amd/csrc/gemm_epi_direct.h", "theia_amd/csrc/gemm_tile.h"]
 
 
 TRAFFIC_WORKLOAD = ("facebook/deit-base-patch16-224", 128, "bf16")  # what tools/pmc_bench_traffic.sh profiles: the default run
@@ -408,8 +411,20 @@ def main(argv=None):
     def step():
         main_loss = fwd_bwd()
         if not args.no_optimizer:
+            if opt.capturable:  # (--graph: the optimizer reads its per-step scalars from the device in eager calls too)
+                opt.prepare_step()
             opt.step()
         return main_loss
+
+    eager_step = step
+    if args.graph:
+        if world > 1 or args.no_optimizer:
+            raise SystemExit("--graph: single process, with the optimizer (the captured step is the whole step)")
+        from theia_amd.train_graph import CapturedTrainStep
+        captured = CapturedTrainStep(model, opt, warmup=2)
+
+        def step():  # noqa: F811  (same synthetic batch every step, like the eager loop: the copy into the static buffers is part of it)
+            return captured(images, targets)["main_loss"]
 
     log("inputs ready")
     if not args.no_selfcheck:
@@ -486,14 +501,14 @@ def main(argv=None):
             """HIP-event durations of every theia_gemm_nt launch over n_steps instrumented steps."""
             ops.GEMM_PROFILE = []
             for _ in range(n_steps):
-                step()
+                eager_step()  # (per-launch HIP events cannot be recorded inside a graph replay)
             torch.cuda.synchronize()
             recs, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
-            return [(e0.elapsed_time(e1) * 1e-3, fl, var, shp) for (e0, e1, fl, var, shp) in recs]
+            return [(e0.elapsed_time(e1) * 1e-3, fl, var, shp, ab) for (e0, e1, fl, var, shp, ab) in recs]
 
         def table(label, rr, NP):
             by = {}
-            for t_, fl, var, shp in rr:
+            for t_, fl, var, shp, *_ab in rr:
                 d = by.setdefault((var,) + shp, [0, 0.0, 0.0])
                 d[0] += 1
                 d[1] += t_
@@ -508,12 +523,13 @@ def main(argv=None):
         recs = measure(NP)  # same regime as the timed steps (weight-gradient kernels overlap on the side stream)
         # the persistent ping-pong kernel (gemm_nt_pp_kernel) runs 256- and 320-row tiles: one kernel, two tile heights
         fam = lambda v: "pingpong" if v in ("256x256", "320x256") else v
-        recs = [(t_, f_, fam(v_), s_) for t_, f_, v_, s_ in recs]
+        recs = [(t_, f_, fam(v_), s_, ab_) for t_, f_, v_, s_, ab_ in recs]
         tot_by_var = {}
-        for t_, _f, v_, _s in recs:
+        for t_, _f, v_, _s, _ab in recs:
             tot_by_var[v_] = tot_by_var.get(v_, 0.0) + t_
         dom_var = max(tot_by_var, key=tot_by_var.get)  # the tile variant with the largest share of the step
-        dom = [(t_, f_) for t_, f_, v_, _s in recs if v_ == dom_var]
+        dom = [(t_, f_) for t_, f_, v_, _s, _ab in recs if v_ == dom_var]
+        alg_bytes = [ab_ for _t, _f, v_, _s, ab_ in recs if v_ == dom_var]
         if want_table:
             table("gemm_nt", recs, NP)
         tsum, fsum = sum(t for t, _ in dom), sum(f for _, f in dom)
@@ -527,11 +543,11 @@ def main(argv=None):
             if want_table:
                 ops.WGRAD_PROFILE = []
             iso_recs = measure(NP)
-            iso = [(t_, f_) for t_, f_, v_, _s in iso_recs if fam(v_) == dom_var]
+            iso = [(t_, f_) for t_, f_, v_, _s, _ab in iso_recs if fam(v_) == dom_var]
             if ops.WGRAD_PROFILE is not None:  # isolated per-shape tables (tuning aid)
                 wrecs, ops.WGRAD_PROFILE = ops.WGRAD_PROFILE, None
                 table("gemm_nt(isolated)", iso_recs, NP)
-                table("gemm_wgrad(isolated)", [(e0.elapsed_time(e1) * 1e-3, fl, var, shp) for (e0, e1, fl, var, shp) in wrecs], NP)
+                table("gemm_wgrad(isolated)", [(e0.elapsed_time(e1) * 1e-3, fl, var, shp, 0) for (e0, e1, fl, var, shp) in wrecs], NP)
             sq.enabled = True
             iso_tf = sum(f for _, f in iso) / sum(t for t, _ in iso) / 1e12
         else:
@@ -541,6 +557,9 @@ def main(argv=None):
         traffic, traffic_src = load_traffic(pfx, (args.backbone, b, args.precision)) if dom_var == "pingpong" else (None, None)
         roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK / 1e12,
                     "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    # minimum HBM bytes per launch (mean over the same launches): operands read once + outputs written once + the
+                    # epilogue's row inputs (ops.gemm_nt_algorithmic_bytes); `traffic` / this = re-read factor
+                    "traffic_algorithmic": round(sum(alg_bytes) / max(1, len(alg_bytes))),
                     "launches_per_step": len(dom) // NP, "avg_launch_us": round(tsum / len(dom) * 1e6, 1),
                     "flops_per_launch": round(fsum / len(dom)),
                     "achieved_isolated": round(iso_tf, 1), "frac_isolated": round(iso_tf * 1e12 / MFMA_BF16_PEAK, 4),
@@ -583,7 +602,7 @@ def main(argv=None):
             "data": "synthetic",
             "config": {"workload": f"{args.backbone.split('/')[-1]} student + {len(TEACHERS)} teacher{'s' if len(TEACHERS) > 1 else ''} ({args.teachers}), per-GPU batch {b}, "
                                    f"loss 0.9*cos+0.1*smoothL1, step = fwd+loss+bwd+grad all-reduce" +
-                                   ("" if args.no_optimizer else "+fused AdamW"),
+                                   ("" if args.no_optimizer else "+fused AdamW") + (", one hipGraph replay per step" if args.graph else ""),
                        "global_batch": b * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
             "settle_steps": settle_steps,
             "host_enqueue_ms_per_step": round(host_dt * 1e3, 3),
@@ -708,7 +727,7 @@ def forward_feature_main(args, rank, world, dev):
                 model.forward_feature(images[:chunk])
         torch.cuda.synchronize()
         recs, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
-        rr = [(e0.elapsed_time(e1) * 1e-3, fl, var) for (e0, e1, fl, var, _s) in recs]
+        rr = [(e0.elapsed_time(e1) * 1e-3, fl, var) for (e0, e1, fl, var, _s, _ab) in recs]
         tot = {}
         for t_, _f, v_ in rr:
             tot[v_] = tot.get(v_, 0.0) + t_

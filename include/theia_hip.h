@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define THEIA_ABI_VERSION 7
+#define THEIA_ABI_VERSION 8
 
 enum { THEIA_OK = 0, THEIA_ERR_INVALID = -1, THEIA_ERR_LAUNCH = -2, THEIA_ERR_UNSUPPORTED = -3 };
 enum { THEIA_F32 = 0, THEIA_BF16 = 1,
@@ -361,6 +361,13 @@ int theia_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, fl
 /* the same with the gradient scale read from device memory (*grad_scale_dev): the clip coefficient of theia_grad_clip_coef */
 int theia_adamw_step_scaled(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                             float eps, float weight_decay, float bias_c1, float bias_c2, const float* grad_scale_dev, void* stream);
+
+/* the same with the per-step scalars read from device memory: hyper_dev = {learning rate, 1 - beta1^t, 1 - beta2^t} (f32 x 3), and an
+ * optional device-resident gradient scale (NULL: 1).  Kernel arguments are frozen when a launch is captured into a hipGraph; with the
+ * scalars that change every step on the device, the optimizer step of train_rvfm.py:131 (+ the scheduler's learning rate, :133) is part
+ * of a captured train step (theia_amd/train_graph.py): the host writes three floats per step and replays. */
+int theia_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                         float weight_decay, const float* hyper_dev, const float* grad_scale_dev, void* stream);
 
 /* dst[i] = float(src_bf16[i]) * scale: widens a bf16 gradient-exchange buffer back into the fp32 gradient bucket after the RCCL
  * all-reduce (the optional bf16 exchange of theia_amd/parallel.py; replaces nothing in the reference, whose DDP exchanges fp32:

@@ -246,3 +246,61 @@ def test_train_script_with_grad_clip(tmp_path):
         FusedAdamW.clip_grad_norm_ = orig
     tl = [v for _, v in hist["train_main_loss"]]
     assert len(seen) == 10 and len(tl) == 2 and all(v == v for v in tl) and tl[-1] < tl[0]
+
+
+@pytest.mark.parametrize("precision,grad_clip", [("bf16", None), ("fp32", 0.5), ("bf16", 0.05)])
+def test_captured_train_step_is_bit_identical_to_the_eager_loop(precision, grad_clip):
+    """theia_amd/train_graph.py: zero_grad + forward + losses + backward (+ clipping) + fused AdamW + operand rebuild captured into one
+    hipGraph.  Two identically initialised models, the same 6 batches, a learning rate that changes every step (the scheduler's job):
+    the eager loop (host-side optimizer scalars) and the captured step (2 eager warm-up calls, then capture + 4 replays; scalars read
+    from the device) must leave BIT-IDENTICAL parameters and report bit-identical losses after every step."""
+    from theia_amd.optimizers import FusedAdamW
+    from theia_amd.train_graph import CapturedTrainStep, default_main_loss
+    ma, teachers = _build(precision)
+    mb, _ = _build(precision)
+    oa = FusedAdamW(ma, lr=1e-3, weight_decay=0.01)
+    ob = FusedAdamW(mb, lr=1e-3, weight_decay=0.01)
+    step_b = CapturedTrainStep(mb, ob, grad_clip=grad_clip, warmup=2)
+    B = 4
+    for i in range(6):
+        images = O.synth_images(B, i).to("cuda:0")
+        targets = {t: v.to("cuda:0") for t, v in O.synth_targets(B, teachers, 100 + i).items()}
+        lr = 1e-3 * (1.0 - 0.1 * i)
+        for o in (oa, ob):
+            o.param_groups[0]["lr"] = lr
+        # eager reference loop (train_rvfm.py:116-131)
+        oa.zero_grad(set_to_none=True)
+        la = ma.get_loss(ma(images), targets, as_float=False)
+        main_a = default_main_loss(la)
+        main_a.backward()
+        if grad_clip is not None:
+            norm_a = oa.clip_grad_norm_(grad_clip)
+        oa.step()
+        out = step_b(images, targets)
+        torch.cuda.synchronize()
+        assert float(out["main_loss"]) == float(main_a), (i, float(out["main_loss"]), float(main_a))
+        for k in ("mse_loss", "cos_loss", "l1_loss"):
+            assert float(out[k]) == float(la[k]), (i, k)
+        if grad_clip is not None:
+            assert float(out["grad_norm"]) == float(norm_a), i
+        for (ka, pa), (_kb, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert torch.equal(pa, pb), (i, ka)
+    assert step_b.replays == 4 and oa.step_count == ob.step_count == 6
+    # the replays changed the parameters behind the host's back: an eager call afterwards must rebuild its operands from them
+    with torch.no_grad():
+        fa = ma.forward_feature(images)
+        fb = mb.forward_feature(images)
+    assert torch.equal(fa, fb)
+
+
+def test_captured_train_step_recaptures_on_a_new_batch_shape():
+    from theia_amd.optimizers import FusedAdamW
+    from theia_amd.train_graph import CapturedTrainStep
+    m, teachers = _build("bf16")
+    step = CapturedTrainStep(m, FusedAdamW(m, lr=1e-3), warmup=1)
+    losses = []
+    for B in (4, 4, 4, 2, 2):
+        images = O.synth_images(B, 0).to("cuda:0")
+        targets = {t: v.to("cuda:0") for t, v in O.synth_targets(B, teachers, 1).items()}
+        losses.append(float(step(images, targets)["main_loss"]))
+    assert step.replays == 4 and all(v == v for v in losses) and losses[2] < losses[0]

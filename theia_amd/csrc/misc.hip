@@ -999,7 +999,12 @@ extern "C" int theia_scatter_tokens(const void* src, void* dst, int b, int nsrc,
 // ------------------------------------------------------------------------------------------------
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gscale,
-                             const float* __restrict__ gscale_dev) {
+                             const float* __restrict__ gscale_dev, const float* __restrict__ hyper_dev) {
+    if (hyper_dev != nullptr) {  // the per-step scalars live on the device (a captured train step: kernel arguments are frozen at capture)
+        lr = hyper_dev[0];
+        bc1 = hyper_dev[1];
+        bc2 = hyper_dev[2];
+    }
     if (gscale_dev != nullptr) gscale *= *gscale_dev;  // clip coefficient computed on the device (theia_grad_clip_coef)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
@@ -1017,7 +1022,7 @@ extern "C" int theia_adamw_step(float* p, const float* g, float* m, float* v, in
                                 float eps, float weight_decay, float bias_c1, float bias_c2, float grad_scale, void* stream) {
     THEIA_CHECK_ARG(p && g && m && v && n > 0, "theia_adamw_step: bad args");
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n, lr,
-                       beta1, beta2, eps, weight_decay, bias_c1, bias_c2, grad_scale, (const float*)nullptr);
+                       beta1, beta2, eps, weight_decay, bias_c1, bias_c2, grad_scale, (const float*)nullptr, (const float*)nullptr);
     THEIA_CHECK_LAUNCH("theia_adamw_step");
     return THEIA_OK;
 }
@@ -1025,8 +1030,16 @@ extern "C" int theia_adamw_step_scaled(float* p, const float* g, float* m, float
                                        float eps, float weight_decay, float bias_c1, float bias_c2, const float* grad_scale_dev, void* stream) {
     THEIA_CHECK_ARG(p && g && m && v && n > 0 && grad_scale_dev, "theia_adamw_step_scaled: bad args");
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n, lr,
-                       beta1, beta2, eps, weight_decay, bias_c1, bias_c2, 1.0f, grad_scale_dev);
+                       beta1, beta2, eps, weight_decay, bias_c1, bias_c2, 1.0f, grad_scale_dev, (const float*)nullptr);
     THEIA_CHECK_LAUNCH("theia_adamw_step_scaled");
+    return THEIA_OK;
+}
+extern "C" int theia_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                                    float weight_decay, const float* hyper_dev, const float* grad_scale_dev, void* stream) {
+    THEIA_CHECK_ARG(p && g && m && v && n > 0 && hyper_dev, "theia_adamw_step_dev: bad args");
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n, 0.f,
+                       beta1, beta2, eps, weight_decay, 1.f, 1.f, 1.0f, grad_scale_dev, hyper_dev);
+    THEIA_CHECK_LAUNCH("theia_adamw_step_dev");
     return THEIA_OK;
 }
 

@@ -127,6 +127,21 @@ GEMM_PROFILE: Optional[list] = None
 WGRAD_PROFILE: Optional[list] = None  # same for theia_gemm_wgrad launches
 
 
+def gemm_nt_algorithmic_bytes(M: int, Nn: int, K: int, rmap: RowMap, esz_in: int, esz_out: int, bias: bool, resid: bool, aux_in: bool,
+                              aux_out: bool) -> int:
+    """Minimum HBM bytes of one theia_gemm_nt launch: every operand element read once, every output element written once.
+    Activations: a plain matrix has M x K elements; a multi-tap (convolution) row map gathers its K = taps x in_c columns from an input
+    of ceil(M / rows per image) images x in_h x in_w x in_c elements (each pixel is read once however many taps touch it).  Weights:
+    N x K.  Outputs: M x N (twice with a saved pre-activation).  Row inputs of the epilogue (residual, GELU' / ReLU' input): M x N each.
+    Bias: 4 N."""
+    R = rmap.rows_h * rmap.rows_w
+    if rmap.ntaps > 1:
+        act = min(M * K, -(-M // R) * rmap.in_h * rmap.in_w * rmap.in_c)
+    else:
+        act = M * rmap.in_c
+    return (esz_in * (act + Nn * K) + esz_out * M * Nn * (1 + int(aux_out) + int(resid) + int(aux_in)) + (4 * Nn if bias else 0))
+
+
 KERNEL_NAMES = {128128: "128x128", 128064: "128x64", 256000: "256x256-2stage", 256256: "256x256", 320256: "320x256", 256009: "256x256-conv"}
 
 
@@ -168,7 +183,9 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int
         e0.record()
         N.check(N.lib().theia_gemm_nt(g, _dt(a), N.stream_ptr()), "theia_gemm_nt")
         e1.record()
-        GEMM_PROFILE.append((e0, e1, 2.0 * M * Nn * K, KERNEL_NAMES.get(N.lib().theia_gemm_nt_plan(g, _dt(a)), "?"), (M, Nn, K)))
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * Nn * K, KERNEL_NAMES.get(N.lib().theia_gemm_nt_plan(g, _dt(a)), "?"), (M, Nn, K),
+                             gemm_nt_algorithmic_bytes(M, Nn, K, rmap, a.element_size(), out.element_size(), bias is not None,
+                                                       resid is not None, aux_in is not None, aux_out is not None)))
         return out
     N.check(N.lib().theia_gemm_nt(g, _dt(a), N.stream_ptr()), "theia_gemm_nt")
     return out
@@ -611,6 +628,12 @@ def adamw_step_scaled(p, g, m, v, lr, beta1, beta2, eps, wd, step: int, grad_sca
     bc2 = 1.0 - beta2 ** step
     N.check(N.lib().theia_adamw_step_scaled(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps, wd,
                                             bc1, bc2, grad_scale_dev.data_ptr(), N.stream_ptr()), "theia_adamw_step_scaled")
+
+
+def adamw_step_dev(p, g, m, v, beta1, beta2, eps, wd, hyper_dev: torch.Tensor, grad_scale_dev: Optional[torch.Tensor] = None) -> None:
+    """adamw_step with (lr, 1 - beta1^t, 1 - beta2^t) read from the 3-element f32 device tensor `hyper_dev` (capturable)"""
+    N.check(N.lib().theia_adamw_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), beta1, beta2, eps, wd,
+                                         hyper_dev.data_ptr(), N.ptr(grad_scale_dev), N.stream_ptr()), "theia_adamw_step_dev")
 
 
 def grad_sumsq(g: torch.Tensor, partials: torch.Tensor) -> None:

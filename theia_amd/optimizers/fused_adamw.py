@@ -27,6 +27,12 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.step_count = 0
         self._clip = None  # (norm, coefficient) device pair set by clip_grad_norm_ and consumed by the next step()
+        # capturable mode (theia_amd/train_graph.py): the scalars that change every step -- learning rate, the two bias corrections --
+        # are read by the update kernel from `_hyper` (3 floats on the device) instead of being kernel arguments, so that a captured
+        # step() can be replayed; `prepare_step()` advances the step counter and refreshes them (one tiny H2D copy, outside the graph)
+        self.capturable = False
+        self._hyper = None
+        self._hyper_host = None
         self.flat_state = []
         for b in self.engine.buckets:
             dev = b.params[0].device
@@ -111,13 +117,38 @@ class FusedAdamW(torch.optim.Optimizer):
         self._clip = out
         return out[0]
 
+    def enable_capturable(self) -> None:
+        if self._hyper is None:
+            dev = self.flat_state[0]["p"].device
+            self._hyper = torch.zeros(3, dtype=torch.float32, device=dev)
+            self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
+        self.capturable = True
+
+    @torch.no_grad()
+    def prepare_step(self) -> None:
+        """capturable mode: advance the step counter and put (lr, 1 - beta1^t, 1 - beta2^t) of the step that is about to run on the
+        device, on the current stream (call right before ``step()`` / before replaying a graph that contains it)"""
+        self.step_count += 1
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        self._hyper_host[0] = float(g["lr"])
+        self._hyper_host[1] = 1.0 - b1 ** self.step_count
+        self._hyper_host[2] = 1.0 - b2 ** self.step_count
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        self.step_count += 1
         g = self.param_groups[0]
         lr, (b1, b2), eps, wd = g["lr"], g["betas"], g["eps"], g["weight_decay"]
         clip, self._clip = self._clip, None
+        if self.capturable:  # the per-step scalars come from the device (prepare_step has run)
+            for b, st, s, e, decay in self._live_runs():
+                ops.adamw_step_dev(st["p"][s:e], b.flat[s:e], st["m"][s:e], st["v"][s:e], b1, b2, eps, wd if decay else 0.0, self._hyper,
+                                   None if clip is None else clip[1:2])
+            _engine_mod.PARAM_EPOCH[0] += 1
+            return loss
+        self.step_count += 1
         for b, st, s, e, decay in self._live_runs():
             if clip is None:
                 ops.adamw_step(st["p"][s:e], b.flat[s:e], st["m"][s:e], st["v"][s:e], lr, b1, b2, eps, wd if decay else 0.0, self.step_count)

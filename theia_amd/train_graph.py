@@ -1,0 +1,114 @@
+"""One whole train step -- zero_grad, student forward, translator heads, distillation losses, backward, (gradient clipping,) fused AdamW
+and the operand rebuild -- captured ONCE into a hipGraph and replayed per step.
+
+Reference loop: scripts/train/train_rvfm.py:116-131 (``pred = rvfm(images); losses = rvfm.module.get_loss(pred, targets);
+main_loss.backward(); clip_grad_norm_; optimizer.step()``).  Eagerly that is ~1500 C-ABI launches per step through ctypes; the host
+needs 11-14 ms to enqueue them.  At the headline configuration (DeiT-base, per-GPU batch 128: 43 ms of GPU time) the enqueue hides
+behind the GPU, but the reference's DEFAULT per-GPU batch is 16 (configs/training/frame_level.yaml:8) and DeiT-tiny's whole step
+at batch 256 is ~15 ms: there the drop-in is host-bound.  Stream capture of the very same launches (no tracing, no re-compilation;
+the side stream of the weight-gradient GEMMs joins the capture through its events) makes a step ONE host call.
+
+What has to live on the device for that: the per-step scalars of the optimizer (learning rate from the scheduler, the two Adam bias
+corrections) -- ``theia_adamw_step_dev`` reads them from a 3-float device tensor that ``FusedAdamW.prepare_step()`` refreshes before
+every replay; the clip coefficient already was device-resident.  Inputs are copied into static buffers in front of the replay;
+the losses come back as 0-d device tensors (reading them is the caller's synchronisation, as with ``get_loss(as_float=False)``).
+
+Single process only: with world size > 1 the gradient exchange (RCCL on a side stream, CU budget switching) stays eager -- use the
+plain loop there.  fp8 mode (host-side calibration of the first use of every scale slot) is not capturable either.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, Optional
+
+import torch
+
+
+def default_main_loss(losses: Dict[str, Any]) -> torch.Tensor:
+    """the reference's default objective (train_rvfm.py:119-122 with main_loss = cos_l1)"""
+    return 0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]
+
+
+class CapturedTrainStep:
+    """``step = CapturedTrainStep(model, optimizer); losses = step(images_uint8, targets)``
+
+    model:      ``RobotVisionFM`` on the GPU (bf16 or fp32 precision);  optimizer: ``FusedAdamW`` over it
+    main_loss:  losses dict -> scalar tensor (default 0.9 cos + 0.1 smooth-L1);  grad_clip: max norm or None
+    warmup:     the first ``warmup`` calls run eagerly (they are real training steps: operand cache, workspaces, kernel attributes and
+                allocator pools exist before the capture); call ``warmup + 1`` captures and replays
+    Returns the dict of ``get_loss(..., as_float=False)`` plus ``"main_loss"`` (and ``"grad_norm"`` with clipping): device tensors that
+    are overwritten by the next call.  A change of input shapes re-captures."""
+
+    def __init__(self, model, optimizer, main_loss: Callable = default_main_loss, grad_clip: Optional[float] = None, warmup: int = 2):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise NotImplementedError("CapturedTrainStep: single-process only (the gradient exchange of theia_amd/parallel.py stays eager)")
+        if getattr(model, "precision", None) == "fp8":
+            raise NotImplementedError("CapturedTrainStep: fp8 mode calibrates its scale slots from the host and is not capturable")
+        self.model, self.opt, self.main_loss, self.grad_clip, self.warmup = model, optimizer, main_loss, grad_clip, int(warmup)
+        self.device = next(model.parameters()).device
+        if self.device.type != "cuda":
+            raise RuntimeError("CapturedTrainStep runs on a ROCm GPU only (no CPU fallback)")
+        optimizer.enable_capturable()
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.calls = 0
+        self.replays = 0
+        self._key = None
+        self._graph = None
+        self._x = None
+        self._y: Dict[str, torch.Tensor] = {}
+        self._out: Dict[str, Any] = {}
+
+    # ------------------------------------------------------------------ the step itself (eager and captured: the same code)
+    def _body(self) -> Dict[str, Any]:
+        self.opt.zero_grad(set_to_none=True)
+        pred = self.model(self._x)
+        losses = self.model.get_loss(pred, self._y, as_float=False)
+        main = self.main_loss(losses)
+        main.backward()
+        out = dict(losses)
+        out["main_loss"] = main.detach()
+        if self.grad_clip is not None:
+            out["grad_norm"] = self.opt.clip_grad_norm_(self.grad_clip)
+        self.opt.step()
+        return out
+
+    def _stage_inputs(self, images: torch.Tensor, targets: Dict[str, torch.Tensor]) -> None:
+        key = (tuple(images.shape), images.dtype) + tuple((t, tuple(v.shape), v.dtype) for t, v in targets.items())
+        if key != self._key:  # first call / new shapes: new static buffers, the old capture (if any) is void
+            self._x = torch.empty_like(images, device=self.device)
+            self._y = {t: torch.empty_like(v, device=self.device) for t, v in targets.items()}
+            self._key, self._graph = key, None
+        self._x.copy_(images, non_blocking=True)
+        for t, v in targets.items():
+            self._y[t].copy_(v, non_blocking=True)
+
+    def __call__(self, images: torch.Tensor, targets: Dict[str, torch.Tensor]) -> Dict[str, Any]:
+        if images.dtype != torch.uint8 or images.dim() != 4:
+            raise TypeError("CapturedTrainStep takes a uint8 [B, H, W, 3] / [B, 3, H, W] image batch")
+        from . import engine as _eng
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        self.calls += 1
+        with torch.cuda.stream(self.stream):
+            self._stage_inputs(images, targets)
+            self.opt.prepare_step()
+            if self.calls <= self.warmup:
+                self._out = self._body()
+            else:
+                if self._graph is None:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.stream):
+                        self._out = self._body()
+                    self._graph = g
+                self._graph.replay()
+                self.replays += 1
+                # the replay updated the parameters behind the host's back: anything that keys on the parameter epoch (the engine's
+                # operand cache in an eager call, StreamedForwardFeature's capture) must see a new one
+                _eng.PARAM_EPOCH[0] += 1
+        cur.wait_stream(self.stream)
+        if images.is_cuda:
+            images.record_stream(self.stream)
+        for v in targets.values():
+            if v.is_cuda:
+                v.record_stream(self.stream)
+        return self._out

@@ -41,7 +41,7 @@ for name, a in agg.items():
 import hashlib, os
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 h = hashlib.sha256()
-for f in ("theia_amd/csrc/gemm_pp.hip", "theia_amd/csrc/gemm_epi_direct.h", "theia_amd/csrc/gemm_tile.h", "theia_amd/csrc/gemm.hip"):
+for f in ("theia_amd/csrc/gemm_pp.hip", "theia_amd/csrc/gemm_epi_direct.h", "theia_amd/csrc/gemm_tile.h"):  # = bench.py NT_KERNEL_SOURCES
     h.update(open(os.path.join(root, f), "rb").read())
 out["_kernel_src_sha"] = h.hexdigest()[:16]
 json.dump(out, open(sys.argv[1].replace("summary.txt", "traffic.json"), "w"), indent=1)
