@@ -422,8 +422,15 @@ def main(argv=None):
             raise SystemExit("--graph: single process, with the optimizer (the captured step is the whole step)")
         from theia_amd.train_graph import CapturedTrainStep
         captured = CapturedTrainStep(model, opt, warmup=2)
+        # the synthetic batch lives in the step's static input buffers (what a data pipeline that ingests straight into them does): the
+        # eager loop reads its resident batch in place too
+        xs, ys = captured.static_inputs(images, targets)
+        xs.copy_(images)
+        for t_ in targets:
+            ys[t_].copy_(targets[t_])
+        images, targets = xs, ys
 
-        def step():  # noqa: F811  (same synthetic batch every step, like the eager loop: the copy into the static buffers is part of it)
+        def step():  # noqa: F811
             return captured(images, targets)["main_loss"]
 
     log("inputs ready")

@@ -179,6 +179,9 @@ int theia_wgrad_fuses_bias(const theia_wgrad_args_t* args, int dtype);
 int theia_gemm_wgrad_plan(const theia_wgrad_args_t* args, int dtype);
 /* recommended number of M-splits for (M, N, kslots*in_c) so that the launch fills the CU budget (theia_get_compute_cus) */
 int theia_wgrad_splits(int M, int N, int Ktot);
+/* the same for a multi-tap map: the kernel's 256 x 256 output tiles do not straddle taps, so a launch has kslots * ceil(in_c / 256) of them
+ * per 256 output columns (in_c = 384: 2 per tap, the second one half used) */
+int theia_wgrad_splits_taps(int M, int N, int kslots, int in_c);
 
 /* out[n*sn + slot*ss + ci*sc] (+)= sum_s slab[s][n][slot*C + ci]   (f32; permutes into the PyTorch layout) */
 int theia_wgrad_reduce(const float* slabs, int splits, int N, int kslots, int C, float* out, int64_t sn,

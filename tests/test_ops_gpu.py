@@ -160,7 +160,8 @@ def test_linear_bias_epilogues(dt, M, N, K, tile):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(197 * 4, 192, 192), (1000, 128, 256), (4096 + 37, 64, 64), (513, 1280, 192), (300, 32, 384), (2049, 24, 128), (777, 8, 64),
-                                   (197 * 9, 768, 768), (2000, 3072, 768), (5000, 256, 768), (96, 1280, 768)])
+                                   (197 * 9, 768, 768), (2000, 3072, 768), (5000, 256, 768), (96, 1280, 768),
+                                   (1500, 384, 384), (777, 1536, 384), (900, 384, 1536), (600, 576, 192), (1111, 192, 768), (650, 1024, 320)])
 def test_linear_wgrad_and_colsum(dt, M, N, K):
     from theia_amd import ops
     dev = _dev()
@@ -203,7 +204,7 @@ def _pack(plan_pack, w, dt, dev):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("kind", ["conv_p1", "convT_s1", "convT_s2_p1", "convT_s2_op1"])
-@pytest.mark.parametrize("C", [64, 256])  # in_c % 256 == 0 is what the ping-pong WEIGHT-GRADIENT kernel needs
+@pytest.mark.parametrize("C", [64, 256, 384, 192])  # the ping-pong WEIGHT-GRADIENT kernel: in_c >= 128; 384 / 192: a partial last c tile
 @pytest.mark.parametrize("tile", TILES + [256009])  # forward / data-gradient GEMMs: library's choice, 2-stage 128x128, 256x256
 # ping-pong, and the one-image-per-tile convolution kernel (256009: the row maps it takes -- 16x16 output, stride 1, 3x3)
 def test_conv_family_fwd_dgrad_wgrad(dt, kind, C, tile):

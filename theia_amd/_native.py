@@ -81,6 +81,7 @@ _SIGNATURES = {
     "theia_gemm_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_int, C.c_void_p]),
     "theia_wgrad_fuses_bias": (C.c_int, [C.POINTER(WgradArgs), C.c_int]),
     "theia_wgrad_splits": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "theia_wgrad_splits_taps": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "theia_gemm_wgrad_plan": (C.c_int, [C.POINTER(WgradArgs), C.c_int]),
     "theia_set_compute_cus": (C.c_int, [C.c_int]),
     "theia_get_compute_cus": (C.c_int, []),

@@ -602,10 +602,12 @@ static bool wgrad_use_pp() {
     return v == 1;
 }
 
-extern "C" int theia_wgrad_splits(int M, int N, int Ktot) {
-    if (wgrad_use_pp() && Ktot % 256 == 0 && N >= 128) {
-        // ping-pong kernel: 256x256 output tiles, one workgroup per CU -> fill one round of the CU budget as exactly as possible
-        const int tiles = cdiv_i(N, 256) * (Ktot / 256);
+extern "C" int theia_wgrad_splits_taps(int M, int N, int kslots, int in_c) {
+    const int Ktot = kslots * in_c;
+    if (wgrad_use_pp() && in_c % 64 == 0 && in_c >= 128 && N >= 128) {
+        // ping-pong kernel: 256x256 output tiles (per tap; the last c tile of a tap may be partial), one workgroup per CU -> fill one
+        // round of the CU budget as exactly as possible
+        const int tiles = cdiv_i(N, 256) * kslots * cdiv_i(in_c, 256);
         int s = theia_compute_cus() / (tiles > 0 ? tiles : 1);
         const int smax = cdiv_i(M, 32) / 8;
         if (s > smax) s = smax;
@@ -621,6 +623,7 @@ extern "C" int theia_wgrad_splits(int M, int N, int Ktot) {
     if (s < 1) s = 1;
     return s;
 }
+extern "C" int theia_wgrad_splits(int M, int N, int Ktot) { return theia_wgrad_splits_taps(M, N, 1, Ktot); }
 
 extern "C" int theia_gemm_wgrad_plan(const theia_wgrad_args_t* a, int dtype) {
     if (a == nullptr) return THEIA_ERR_INVALID;

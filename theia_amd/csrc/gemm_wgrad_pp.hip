@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     const int wm = wave >> 2, wn = wave & 3;   // wm: which 128 c-columns (= wave group), wn: which 64 n-columns
     const theia_rowmap_t& mp = p.map;
     const int tiles_n = (p.N + 255) / 256;
-    const int tiles_c = mp.in_c / 256;
+    const int tiles_c = (mp.in_c + 255) / 256;  // (the last c tile may be partial: in_c = 384, 192 -- columns past in_c read zeros and are not stored)
     const int ntile = tiles_n * mp.ntaps * tiles_c;
     // hardware places block b on XCD b % 8: give each XCD a contiguous range of (split, tile) so that the workgroups sharing a dY
     // column tile or an activation (tap, c) tile meet in one L2 (THEIA_WGRAD_XCD=0: A/B switch, plain order)
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     const int lb = (pb & 8) | ((pb & 7) ^ (srow & 7));
     const int col = (lb * 2 + (s16 & 1)) * 8;            // element column inside the 256-wide tile
     const bool n_ok = n0 + col < p.N;
+    const bool c_ok = c0 + col < mp.in_c;
     const float rcpW = 1.0f / (float)mp.rows_w, rcpH = 1.0f / (float)mp.rows_h;
     int st_m[2], st_img[2], st_ry[2], st_rx[2];
 #pragma unroll
@@ -152,20 +153,20 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
         uint64_t sy, sx;
         if constexpr (MODE == 1) {
             sy = (mok & n_ok) ? f_py[i] : zp;
-            sx = mok ? f_px[i] : zp;
+            sx = (mok & c_ok) ? f_px[i] : zp;
         } else if constexpr (MODE == 2) {
-            const bool xok = mok & (((vmask[i] >> phase[i]) & 1u) != 0u);
+            const bool xok = mok & c_ok & (((vmask[i] >> phase[i]) & 1u) != 0u);
             sy = (mok & n_ok) ? f_py[i] : zp;
             sx = xok ? f_px[i] : zp;
         } else if constexpr (fast) {
-            const bool xok = mok & ((unsigned)(st_ry[i] - ry_lo) < ry_span) & ((unsigned)(st_rx[i] - rx_lo) < rx_span);
+            const bool xok = mok & c_ok & ((unsigned)(st_ry[i] - ry_lo) < ry_span) & ((unsigned)(st_rx[i] - rx_lo) < rx_span);
             sy = (mok & n_ok) ? f_py[i] : zp;
             sx = xok ? f_px[i] : zp;
         } else {
             const int64_t oy = (int64_t)st_img[i] * mp.out_batch_stride + mp.out_offset +
                                (int64_t)((st_ry[i] * mp.out_sy + mp.out_y0) * mp.out_w + st_rx[i] * mp.out_sx + mp.out_x0) * p.ldo + n0 + col;
             const int iy = st_ry[i] * mp.in_sy + dy, ix = st_rx[i] * mp.in_sx + dx;
-            const bool xok = mok & (iy >= 0) & (iy < mp.in_h) & (ix >= 0) & (ix < mp.in_w);
+            const bool xok = mok & c_ok & (iy >= 0) & (iy < mp.in_h) & (ix >= 0) & (ix < mp.in_w);
             const int64_t ox = (int64_t)st_img[i] * mp.in_batch_stride + mp.in_offset + (int64_t)(iy * mp.in_w + ix) * mp.in_c + c0 + col;
             const uint64_t my = 0ull - (uint64_t)(mok & n_ok), mx = 0ull - (uint64_t)xok;
             sy = (reinterpret_cast<uint64_t>(DY + oy) & my) | (zp & ~my);
@@ -310,9 +311,10 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
         const int n = n0 + wn * 64 + i * 16 + q;
         if (n >= p.N) continue;
         float* drow = slab + (int64_t)n * krow + (int64_t)mp.wslot[tap] * mp.in_c + c0 + wm * 128 + g * 4;
+        const int c_left = mp.in_c - (c0 + wm * 128 + g * 4);  // columns of this lane's first float4 up to the end of the tap's c range
 #pragma unroll
         for (int j = 0; j < FM; ++j)
-            *reinterpret_cast<float4*>(drow + j * 16) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            if (j * 16 < c_left) *reinterpret_cast<float4*>(drow + j * 16) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     }
 }
 
@@ -326,7 +328,8 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
     out[n] = accumulate ? out[n] + s : s;
 }
 
-bool theia_gemm_wgrad_pp_supported(const theia_wgrad_args_t* a) { return a->map.in_c % 256 == 0 && a->N >= 128; }
+// in_c a multiple of 64 (the last of ceil(in_c / 256) c tiles may be partial: DeiT-small's 384, DeiT-tiny's 192), at least half a tile of n
+bool theia_gemm_wgrad_pp_supported(const theia_wgrad_args_t* a) { return a->map.in_c % 64 == 0 && a->map.in_c >= 128 && a->N >= 128; }
 
 // Which row addressing the launch will use (host logic only; exported through theia_gemm_wgrad_plan): 0 = per-row decode (the maps
 // the stepping path cannot take), 10 = stepping (mode 0), 11 = plain matrices (mode 1), 12 = periodic (mode 2).  -1: not this kernel.
@@ -361,7 +364,7 @@ int theia_gemm_wgrad_pp_mode(const theia_wgrad_args_t* a) {
     return 10;
 }
 
-// bf16 only; requires in_c % 256 == 0.  Returns THEIA_ERR_UNSUPPORTED when the shape does not qualify.
+// bf16 only; requires in_c % 64 == 0.  Returns THEIA_ERR_UNSUPPORTED when the shape does not qualify.
 int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) {
     if (!theia_gemm_wgrad_pp_supported(a)) return THEIA_ERR_UNSUPPORTED;
     constexpr int lds4 = 4 * 2 * 32 * 512, lds5 = 5 * 2 * 32 * 512;
@@ -381,7 +384,7 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
         const char* e = getenv("THEIA_WGRAD_STAGES");
         stages = e != nullptr && atoi(e) == 5 ? 5 : 4;
     }
-    const int tiles = cdiv_i(a->N, 256) * a->map.ntaps * (a->map.in_c / 256);
+    const int tiles = cdiv_i(a->N, 256) * a->map.ntaps * cdiv_i(a->map.in_c, 256);
     static int issue_in_m = -1;
     if (issue_in_m < 0) {
         const char* e = getenv("THEIA_WGRAD_ISSUE");

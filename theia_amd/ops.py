@@ -300,7 +300,7 @@ def wgrad_finish(slabs: torch.Tensor, splits: int, Nn: int, kslots: int, C: int,
 def conv_wgrad_splits(plan: ConvPlan, b: int, C: int) -> int:
     """split count conv_wgrad will use (slab workspace = splits * 9 * C * C floats)."""
     mpi = plan.dgrad[1] if plan.wgrad_swapped else sum(m for _r, m in plan.fwd)
-    return wgrad_splits(b * mpi, C, 9 * C)
+    return N.lib().theia_wgrad_splits_taps(b * mpi, C, 9, C)
 
 
 def conv_wgrad(plan: ConvPlan, dy: torch.Tensor, x: torch.Tensor, b: int, C: int, grad_w: torch.Tensor, accumulate: bool,

@@ -72,15 +72,25 @@ class CapturedTrainStep:
         self.opt.step()
         return out
 
-    def _stage_inputs(self, images: torch.Tensor, targets: Dict[str, torch.Tensor]) -> None:
+    def static_inputs(self, images: torch.Tensor, targets: Dict[str, torch.Tensor]):
+        """The static device buffers the captured step reads, shaped like ``images`` / ``targets`` (allocated on first use; a new shape
+        voids the capture).  A data pipeline that writes its batches straight into them (H2D copies from pinned memory, the feature
+        ingest kernel) and then calls ``step(x_static, y_static)`` with these very tensors pays no staging copy -- at DeiT-base, 5
+        teachers, batch 128 the f32 teacher features of one step are 1 GB."""
         key = (tuple(images.shape), images.dtype) + tuple((t, tuple(v.shape), v.dtype) for t, v in targets.items())
         if key != self._key:  # first call / new shapes: new static buffers, the old capture (if any) is void
             self._x = torch.empty_like(images, device=self.device)
             self._y = {t: torch.empty_like(v, device=self.device) for t, v in targets.items()}
             self._key, self._graph = key, None
-        self._x.copy_(images, non_blocking=True)
+        return self._x, self._y
+
+    def _stage_inputs(self, images: torch.Tensor, targets: Dict[str, torch.Tensor]) -> None:
+        self.static_inputs(images, targets)
+        if images is not self._x:
+            self._x.copy_(images, non_blocking=True)
         for t, v in targets.items():
-            self._y[t].copy_(v, non_blocking=True)
+            if v is not self._y[t]:
+                self._y[t].copy_(v, non_blocking=True)
 
     def __call__(self, images: torch.Tensor, targets: Dict[str, torch.Tensor]) -> Dict[str, Any]:
         if images.dtype != torch.uint8 or images.dim() != 4:
