@@ -258,8 +258,8 @@ static int check_rowmap(const theia_rowmap_t& m, int kt, const char* who) {
 // score = useful fraction of the padded tile grid x fill of the last block wave x relative per-CU rate.
 extern "C" int theia_gemm_nt_tile(int M, int N, int dtype) {
     const int t128 = cdiv_i(N, 128) * 128;
-    if ((t128 - N) * 8 > t128) return 128064;
-    if (dtype != THEIA_BF16) return 128128;
+    const bool narrow = (t128 - N) * 8 > t128;  // a 128-wide N tile would waste > 12 % of the MFMA work: 128x64 among the 2-stage tiles
+    if (dtype != THEIA_BF16) return narrow ? 128064 : 128128;
     static int force = -1;
     if (force < 0) {
         const char* e = getenv("THEIA_GEMM_TILE");
@@ -272,8 +272,13 @@ extern "C" int theia_gemm_nt_tile(int M, int N, int dtype) {
         const double fill = blocks / (cdiv_i((long)blocks, slots) * (double)slots);
         return useful * fill * rate;
     };
-    const bool big = force == 256 || (force == 0 && score(256, 256, 256, 1.0) > score(128, 128, 512, 0.6));
-    return big ? 256256 : 128128;
+    // Relative per-CU rates of the kernels behind the tiles, from the bench tables: the persistent ping-pong kernel 1.0 (600-1200 TF on the
+    // shapes of the step), the 2-stage 128x128 kernel 0.6 of that, the 2-stage 128x64 kernel 0.25 (DeiT-tiny's N = 192 launches ran it at
+    // ~90 TF: 22 % of that model's step until round 4 -- a 256-wide tile that is 3/4 full beats it 3x).  Ties go to the smaller tile.
+    const double s256 = score(256, 256, 256, 1.0);
+    const double s2 = narrow ? score(128, 64, 512, 0.25) : score(128, 128, 512, 0.6);
+    const bool big = force == 256 || (force == 0 && s256 > s2 * 1.0001);
+    return big ? 256256 : (narrow ? 128064 : 128128);
 }
 
 // Which kernel theia_gemm_nt runs for these arguments: 128128 / 128064 = 2-stage kernel with that tile, 256000 = 2-stage kernel

@@ -317,12 +317,15 @@ int theia_gemm_conv_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t
     const long full = (long)images * tn;
     const double cost_plain = (double)cdiv_i(full, cus);
     const double cost_split = (double)cdiv_i((long)images * (tn - 1), cus) + 0.6 * (double)cdiv_i((long)images * 2, cus);
-    if (split_ok && tn >= 2 && a->N % 256 == 0 && cost_split < cost_plain - 0.05) {
+    // N = 256 k + 128 (DeiT-small's 384 channels): the last 128 columns ARE one 128-column tile per image -- always split (the plain grid
+    // would run them as half-empty 256-column tiles)
+    const bool tail128 = tn >= 2 && a->N % 256 == 128;
+    if (split_ok && tn >= 2 && (tail128 || (a->N % 256 == 0 && cost_split < cost_plain - 0.05))) {
         theia_gemm_args_t lo = *a, hi = *a;
         const int ncut = (tn - 1) * 256;
         const int esz = dtype == THEIA_BF16 ? 2 : 4;
         lo.N = ncut;
-        hi.N = 256;
+        hi.N = a->N - ncut;
         hi.w = static_cast<const char*>(a->w) + (size_t)ncut * a->ldw * esz;
         hi.out = static_cast<char*>(a->out) + (size_t)ncut * esz;
         if (a->bias != nullptr) hi.bias = a->bias + ncut;
