@@ -616,7 +616,9 @@ def main(argv=None):
             "rccl_ranks": rccl_ranks,
             "dp": None if world == 1 else {"exchange": ddp.reducer.exchange, "comm_dtype": ddp.reducer.comm_dtype,
                                            "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
-                                           "cus_left_to_rccl_during_backward": ddp._reserve},
+                                           "cus_left_to_rccl_during_backward": ddp._reserve,
+                                           # exchange order = backward-completion order; MB of fp32 per bucket
+                                           "buckets_mb": [[bk.name, round(bk.numel * 4 / 1e6, 1)] for bk in model.engine.buckets]},
             "selfcheck": checks if checks else "skipped (--no-selfcheck): unchecked run",
             "model_flops_utilization": round(value / world * FLOPS_PER_IMAGE[(args.backbone, args.teachers)] / MFMA_BF16_PEAK, 4)
             if FLOPS_PER_IMAGE.get((args.backbone, args.teachers)) else None,

@@ -33,11 +33,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ret, backend="gloo"):
+def _worker(rank, world, port, ret, backend="gloo", exchange="allreduce", comm_dtype="fp32"):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["THEIA_DP_EXCHANGE"] = exchange
+    os.environ["THEIA_DP_COMM_DTYPE"] = comm_dtype
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend == "nccl":
         torch.cuda.set_device(rank)
@@ -90,14 +92,17 @@ def _worker(rank, world, port, ret, backend="gloo"):
 
 
 @two_gpus
-def test_dp2_rccl_matches_single_process_gradient():
+@pytest.mark.parametrize("exchange,comm_dtype", [("allreduce", "fp32"), ("rs_ag", "fp32"), ("allreduce", "bf16"), ("rs_ag", "bf16")])
+def test_dp2_rccl_matches_single_process_gradient(exchange, comm_dtype):
+    """every exchange variant of GradBucketReducer over RCCL (runs where >= 2 GPUs are visible): the in-place reduce_scatter_tensor into
+    the rank's own shard + all-gather, and the bf16 wire with the AVG reduction, are RCCL-only branches (gloo substitutes them)"""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), ret, "nccl"), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), ret, "nccl", exchange, comm_dtype), nprocs=2, join=True)
     assert ret["backend"] == "nccl" and ret["world"] == 2
     assert ret["n"] > 100
     name, err = ret["worst"]
-    assert err < 2e-4, (name, err)
+    assert err < (2e-4 if comm_dtype == "fp32" else 1e-2), (name, err)
 
 
 @two_gpus

@@ -320,7 +320,9 @@ class StudentEngine:
             pre = f"translator.translator_heads.{tr.legit_target_model_name_map[t]}."
             self.buckets.append(GradBucket(f"head:{t}", [(pre + n, p) for n, p in hm.named_parameters()]))
         vit = self.rvfm.backbone.model
-        groups = [(9, 12), (6, 9), (3, 6), (0, 3)]
+        # three-layer groups from the top; the LAST layers to finish (2, 1, 0 + embeddings) are buckets of their own: what is still
+        # to be exchanged when backward ends is one layer (28 MB of fp32 for DeiT-base) instead of three + embeddings (88 MB)
+        groups = [(9, 12), (6, 9), (3, 6), (2, 3), (1, 2), (0, 1)]
         for gi, (lo, hi) in enumerate(groups):
             ps: List[Tuple[str, torch.nn.Parameter]] = []
             if gi == 0:
@@ -649,8 +651,8 @@ class StudentEngine:
 
         hL, meanf, rstdf = saved["final"]
         dh = self._ln_bwd(dz, hL, vit.layernorm, meanf, rstdf, None, ws)
-        vit_buckets = [bk for bk in self.buckets if bk.name.startswith("vit:")]  # layer groups 9-11, 6-8, 3-5, 0-2
-        group_lo = {9: vit_buckets[0], 6: vit_buckets[1], 3: vit_buckets[2]}
+        vit_buckets = [bk for bk in self.buckets if bk.name.startswith("vit:")]  # layer groups 9-11, 6-8, 3-5, then 2, 1, 0 (+ embeddings)
+        group_lo = {int(bk.name[4:].split("-")[0]): bk for bk in vit_buckets[:-1]}  # lowest layer of a group -> its bucket
         for i in range(NUM_LAYERS - 1, -1, -1):
             L = vit.layers[i]
             (h, mean1, rstd1, a, qkv, o, lse, h1, mean2, rstd2, m, pre, act) = saved["layers"][i]
@@ -724,7 +726,7 @@ class StudentEngine:
         slabs = ws[: splits * D * 768]
         ops.gemm_wgrad(dh, saved["patches"], slabs, Mp, D, D, 1, splits, rmap)
         ops.wgrad_finish(slabs, splits, D, 1, 768, gpw, 768, 0, 1, acc)
-        self._bucket_done(vit_buckets[3], side)
+        self._bucket_done(vit_buckets[-1], side)
 
     def _ln_bwd(self, dy, x, ln, mean, rstd, dresid, ws):
         """row-LayerNorm backward with the affine gradients written to the bucket.  The kernel takes ONE accumulate flag for weight and
