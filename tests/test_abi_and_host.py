@@ -276,7 +276,8 @@ def test_model_state_dict_buckets_and_decay_rule():
             seen.add(id(p))
             assert (b.offsets[i] < b.decay_numel) == (id(p) not in nodecay), n
     assert seen == {id(p) for p in m.parameters()}
-    assert [b.name.split(":")[0] for b in m.engine.buckets] == ["head"] * 5 + ["vit"] * 4
+    assert [b.name for b in m.engine.buckets][5:] == ["vit:9-11", "vit:6-8", "vit:3-5", "vit:2-2", "vit:1-1", "vit:0-0"]
+    assert [b.name.split(":")[0] for b in m.engine.buckets] == ["head"] * 5 + ["vit"] * 6
     with pytest.raises(RuntimeError):
         m.forward_feature(O.synth_images(1))  # CPU model: the product path refuses, it never falls back
 
