@@ -29,10 +29,9 @@ class FusedAdamW(torch.optim.Optimizer):
         self._clip = None  # (norm, coefficient) device pair set by clip_grad_norm_ and consumed by the next step()
         # capturable mode (theia_amd/train_graph.py): the scalars that change every step -- learning rate, the two bias corrections --
         # are read by the update kernel from `_hyper` (3 floats on the device) instead of being kernel arguments, so that a captured
-        # step() can be replayed; `prepare_step()` advances the step counter and refreshes them (one tiny H2D copy, outside the graph)
+        # step() can be replayed; `prepare_step()` advances the step counter and refreshes them (three fill launches outside the graph)
         self.capturable = False
         self._hyper = None
-        self._hyper_host = None
         self.flat_state = []
         for b in self.engine.buckets:
             dev = b.params[0].device
@@ -121,7 +120,6 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._hyper is None:
             dev = self.flat_state[0]["p"].device
             self._hyper = torch.zeros(3, dtype=torch.float32, device=dev)
-            self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
         self.capturable = True
 
     @torch.no_grad()
@@ -131,10 +129,12 @@ class FusedAdamW(torch.optim.Optimizer):
         self.step_count += 1
         g = self.param_groups[0]
         b1, b2 = g["betas"]
-        self._hyper_host[0] = float(g["lr"])
-        self._hyper_host[1] = 1.0 - b1 ** self.step_count
-        self._hyper_host[2] = 1.0 - b2 ** self.step_count
-        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        # three fill launches: the scalars travel as KERNEL ARGUMENTS (copied at launch).  An asynchronous copy from one pinned host buffer
+        # raced with the host, which runs several steps ahead of the GPU and overwrote the buffer before the copy had executed -- step t
+        # then used step t+k's learning rate (caught by the train-script test, which does not synchronise every step)
+        self._hyper[0:1].fill_(float(g["lr"]))
+        self._hyper[1:2].fill_(1.0 - b1 ** self.step_count)
+        self._hyper[2:3].fill_(1.0 - b2 ** self.step_count)
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -102,6 +102,15 @@ def train(rvfm: nn.Module, target_model_names, optimizer, lr_scheduler, train_it
     log_interval = int(cfg.logging.get("log_interval", 10))
     steps = 0
     history = {"train_main_loss": [], "eval_main_loss": []}
+    # training.capture_step=true (no reference equivalent; single process): the loop body below -- forward, get_loss, backward, clipping,
+    # optimizer.step -- runs as ONE hipGraph replay per step (theia_amd/train_graph.py); it pays where the eager loop is host-bound,
+    # i.e. at the reference's default per-GPU batch of 16 (configs/training/frame_level.yaml:8)
+    captured = None
+    if cfg.training.get("capture_step", False):
+        if (dist.is_initialized() and dist.get_world_size() > 1) or not isinstance(optimizer, FusedAdamW):
+            raise NotImplementedError("training.capture_step needs a single process and the fused optimizer")
+        from theia_amd.train_graph import CapturedTrainStep
+        captured = CapturedTrainStep(rvfm.module, optimizer, main_loss=lambda l: select_main_loss(l, cfg.training.main_loss), warmup=2)
     for ep in range(cfg.training.epochs):
         rvfm.train()
         t0 = time.time()
@@ -111,18 +120,24 @@ def train(rvfm: nn.Module, target_model_names, optimizer, lr_scheduler, train_it
             if cfg.training.random_target_models > 0:
                 raise NotImplementedError("random_target_models > 0 is not supported (breaks data-parallel reduction in the reference too)")
             target_features_batch = _targets_of(batch, target_model_names)
-            pred = rvfm(images_batch)
-            losses = rvfm.module.get_loss(pred, target_features_batch, as_float=False)
-            main_loss = select_main_loss(losses, cfg.training.main_loss)
-            optimizer.zero_grad()
-            main_loss.backward()
+            max_norm = None
             if cfg.training.grad_clip:
                 max_norm = cfg.training.grad_clip_norm_warmup if steps < warmup_steps else cfg.training.grad_clip_norm
-                if isinstance(optimizer, FusedAdamW):  # global norm + clip factor on the device, applied inside the AdamW kernel
-                    optimizer.clip_grad_norm_(max_norm)
-                else:
-                    nn.utils.clip_grad_norm_(rvfm.parameters(), max_norm)
-            optimizer.step()
+            if captured is not None:
+                captured.set_grad_clip(max_norm)
+                main_loss = captured(images_batch, target_features_batch)["main_loss"]
+            else:
+                pred = rvfm(images_batch)
+                losses = rvfm.module.get_loss(pred, target_features_batch, as_float=False)
+                main_loss = select_main_loss(losses, cfg.training.main_loss)
+                optimizer.zero_grad()
+                main_loss.backward()
+                if max_norm is not None:
+                    if isinstance(optimizer, FusedAdamW):  # global norm + clip factor on the device, applied inside the AdamW kernel
+                        optimizer.clip_grad_norm_(max_norm)
+                    else:
+                        nn.utils.clip_grad_norm_(rvfm.parameters(), max_norm)
+                optimizer.step()
             if lr_scheduler is not None:
                 lr_scheduler.step()
             steps += 1
@@ -133,6 +148,8 @@ def train(rvfm: nn.Module, target_model_names, optimizer, lr_scheduler, train_it
                       f"({(time.time() - t0) / max(1, steps % train_epoch_steps or train_epoch_steps) * 1e3:.1f} ms/step)", flush=True)
             if cfg.training.freeze_translator and steps == int(cfg.training.freeze_translator_start_steps_ratio * total_train_steps):
                 rvfm.module.freeze_translator()
+                if captured is not None:
+                    captured.invalidate()
             if steps % cfg.logging.save_ckpt_interval == 0 and rank == 0:
                 save_checkpoint(rvfm.module, cfg, steps)
         if dist.is_initialized():

@@ -58,6 +58,17 @@ class CapturedTrainStep:
         self._y: Dict[str, torch.Tensor] = {}
         self._out: Dict[str, Any] = {}
 
+    def set_grad_clip(self, max_norm: Optional[float]) -> None:
+        """change the clipping threshold (train_rvfm.py:126-130 switches from grad_clip_norm_warmup to grad_clip_norm after the warm-up
+        steps): the threshold is a launch argument of the captured clip kernel, so a new value voids the capture"""
+        if max_norm != self.grad_clip:
+            self.grad_clip = max_norm
+            self._graph = None
+
+    def invalidate(self) -> None:
+        """void the capture (e.g. after ``freeze_translator()``: which parameters have gradients is baked into the captured step)"""
+        self._graph = None
+
     # ------------------------------------------------------------------ the step itself (eager and captured: the same code)
     def _body(self) -> Dict[str, Any]:
         self.opt.zero_grad(set_to_none=True)
