@@ -337,6 +337,15 @@ class StudentEngine:
             for i, p in enumerate(b.params):
                 self._bucket_of[id(p)] = (b, i)
 
+    def _cached_params(self, key: str, module: torch.nn.Module) -> List[torch.nn.Parameter]:
+        """list(module.parameters()), walked once: the module tree walk cost 0.5 ms of host time per step (tools/host_profile.py).  The
+        buckets built at construction already assume that the Parameter objects of the model stay the ones they were."""
+        c = self.__dict__.setdefault("_param_lists", {})
+        hit = c.get(key)
+        if hit is None or hit[0] is not module:
+            hit = c[key] = (module, list(module.parameters()))
+        return hit[1]
+
     def all_params(self) -> List[torch.nn.Parameter]:
         return [p for b in self.buckets for p in b.params]
 
@@ -537,7 +546,7 @@ class StudentEngine:
         geo = self.geo224 if (gh, gw, interp) == (GRID, GRID, False) else Geometry(gh, gw, self.tok0, self.nreg, interp)
         if geo.ntok > MAX_TOKENS:
             raise NotImplementedError(f"{hh}x{ww} input = {geo.ntok} tokens: the attention kernels hold at most {MAX_TOKENS}")
-        params = list(vit.parameters())
+        params = self._cached_params("vit", vit)
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _BackboneFn.apply(self, img, channels_last, do_rescale, do_normalize, geo, *params)
         if self.fp8 is not None:
@@ -786,7 +795,7 @@ class StudentEngine:
                 raise KeyError(t)
         head_params: List[torch.nn.Parameter] = []
         for t in names:
-            head_params += list(tr.translator_heads[tr.legit_target_model_name_map[t]].parameters())
+            head_params += self._cached_params("head:" + t, tr.translator_heads[tr.legit_target_model_name_map[t]])
         if z.dtype != self.dtype:
             raise TypeError(f"feature dtype {z.dtype} does not match the engine's compute dtype {self.dtype}")
         if torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in head_params)):

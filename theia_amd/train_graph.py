@@ -6,7 +6,7 @@ main_loss.backward(); clip_grad_norm_; optimizer.step()``).  Eagerly that is ~15
 needs 11-14 ms to enqueue them.  At the headline configuration (DeiT-base, per-GPU batch 128: 43 ms of GPU time) the enqueue hides
 behind the GPU, but the reference's DEFAULT per-GPU batch is 16 (configs/training/frame_level.yaml:8) and DeiT-tiny's whole step
 at batch 256 is ~15 ms: there the drop-in is host-bound.  Stream capture of the very same launches (no tracing, no re-compilation;
-the side stream of the weight-gradient GEMMs joins the capture through its events) makes a step ONE host call.
+single-stream: the weight-gradient side queue runs inline inside the capture) makes a step ONE host call.
 
 What has to live on the device for that: the per-step scalars of the optimizer (learning rate from the scheduler, the two Adam bias
 corrections) -- ``theia_adamw_step_dev`` reads them from a 3-float device tensor that ``FusedAdamW.prepare_step()`` refreshes before
@@ -44,7 +44,7 @@ class CapturedTrainStep:
             raise NotImplementedError("CapturedTrainStep: single-process only (the gradient exchange of theia_amd/parallel.py stays eager)")
         if getattr(model, "precision", None) == "fp8":
             raise NotImplementedError("CapturedTrainStep: fp8 mode calibrates its scale slots from the host and is not capturable")
-        self.model, self.opt, self.main_loss, self.grad_clip, self.warmup = model, optimizer, main_loss, grad_clip, int(warmup)
+        self.model, self.opt, self.main_loss, self.grad_clip, self.warmup = model, optimizer, main_loss, grad_clip, max(1, int(warmup))
         self.device = next(model.parameters()).device
         if self.device.type != "cuda":
             raise RuntimeError("CapturedTrainStep runs on a ROCm GPU only (no CPU fallback)")
@@ -117,9 +117,23 @@ class CapturedTrainStep:
                 self._out = self._body()
             else:
                 if self._graph is None:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=self.stream):
-                        self._out = self._body()
+                    # The capture is SINGLE-STREAM: the engine's side queue (weight gradients on a second stream, joined through events) is
+                    # switched to inline for the duration.  A capture that forks and joins through events replays correctly, but on ROCm 7.0
+                    # destroying such a graph corrupts the host heap ("double free or corruption" within a few create / destroy cycles:
+                    # tools/stress_captured_step.py; none in 80 cycles single-stream) -- and it buys nothing: the replay runs the
+                    # weight-gradient branch without overlap anyway.  Same kernels in the same order: bit-identical results.
+                    sq = getattr(self.model.engine, "_sideq", None)
+                    was = None
+                    if sq is not None:
+                        sq.join()
+                        was, sq.enabled = sq.enabled, False
+                    try:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=self.stream):
+                            self._out = self._body()
+                    finally:
+                        if sq is not None:
+                            sq.enabled = was
                     self._graph = g
                 self._graph.replay()
                 self.replays += 1
