@@ -32,7 +32,14 @@ def main():
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--tile", type=int, default=0, help="kernel request for theia_gemm_nt (0 = library's choice)")
     ap.add_argument("--fp8", action="store_true", help="fp8 e4m3 operands (plain shapes, nt only)")
+    ap.add_argument("--mnk", default="", help='extra plain shapes "M,N,K;M,N,K;..." (replaces --shapes)')
     a = ap.parse_args()
+    if a.mnk:
+        SHAPES.clear()
+        for i, t in enumerate(a.mnk.split(";")):
+            M_, N_, K_ = (int(v) for v in t.split(","))
+            SHAPES[f"s{i}"] = (M_, N_, K_, "plain")
+        a.shapes = ",".join(SHAPES)
     dev = torch.device("cuda:0")
     T = torch.bfloat16
     for name in a.shapes.split(","):
