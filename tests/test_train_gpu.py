@@ -345,3 +345,24 @@ def test_captured_steps_can_be_created_and_destroyed_repeatedly():
         del step, m, out
         if it % 3 == 0:
             gc.collect()
+
+
+def test_capturable_optimizer_used_eagerly_matches_the_plain_one():
+    """enable_capturable() moves the per-step scalars to the device; an eager step() without prepare_step() refreshes them itself"""
+    from theia_amd.optimizers import FusedAdamW
+    ma, teachers = _build("bf16")
+    mb, _ = _build("bf16")
+    oa, ob = FusedAdamW(ma, lr=1e-3, weight_decay=0.01), FusedAdamW(mb, lr=1e-3, weight_decay=0.01)
+    ob.enable_capturable()
+    for i in range(3):
+        images = O.synth_images(2, i).to("cuda:0")
+        targets = {t: v.to("cuda:0") for t, v in O.synth_targets(2, teachers, i).items()}
+        for m, o in ((ma, oa), (mb, ob)):
+            o.param_groups[0]["lr"] = 1e-3 / (i + 1)
+            o.zero_grad()
+            losses = m.get_loss(m(images), targets, as_float=False)
+            (0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]).backward()
+            o.step()
+    assert oa.step_count == ob.step_count == 3
+    for (k, pa), (_k, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.equal(pa, pb), k

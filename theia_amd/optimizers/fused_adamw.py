@@ -132,6 +132,7 @@ class FusedAdamW(torch.optim.Optimizer):
         # three fill launches: the scalars travel as KERNEL ARGUMENTS (copied at launch).  An asynchronous copy from one pinned host buffer
         # raced with the host, which runs several steps ahead of the GPU and overwrote the buffer before the copy had executed -- step t
         # then used step t+k's learning rate (caught by the train-script test, which does not synchronise every step)
+        self._prepared = True
         self._hyper[0:1].fill_(float(g["lr"]))
         self._hyper[1:2].fill_(1.0 - b1 ** self.step_count)
         self._hyper[2:3].fill_(1.0 - b2 ** self.step_count)
@@ -142,7 +143,12 @@ class FusedAdamW(torch.optim.Optimizer):
         g = self.param_groups[0]
         lr, (b1, b2), eps, wd = g["lr"], g["betas"], g["eps"], g["weight_decay"]
         clip, self._clip = self._clip, None
-        if self.capturable:  # the per-step scalars come from the device (prepare_step has run)
+        if self.capturable:  # the per-step scalars come from the device
+            # an eager step() of a capturable optimizer without prepare_step() (e.g. user code between two captured phases) refreshes
+            # them itself; inside a capture they must already be in place (CapturedTrainStep calls prepare_step before every replay)
+            if not getattr(self, "_prepared", False) and not torch.cuda.is_current_stream_capturing():
+                self.prepare_step()
+            self._prepared = False
             for b, st, s, e, decay in self._live_runs():
                 ops.adamw_step_dev(st["p"][s:e], b.flat[s:e], st["m"][s:e], st["v"][s:e], b1, b2, eps, wd if decay else 0.0, self._hyper,
                                    None if clip is None else clip[1:2])

@@ -136,6 +136,7 @@ class CapturedTrainStep:
                             sq.enabled = was
                     self._graph = g
                 self._graph.replay()
+                self.opt._prepared = False  # (consumed by the replayed step)
                 self.replays += 1
                 # the replay updated the parameters behind the host's back: anything that keys on the parameter epoch (the engine's
                 # operand cache in an eager call, StreamedForwardFeature's capture) must see a new one
