@@ -614,7 +614,7 @@ def main(argv=None):
             "settle_steps": settle_steps,
             "host_enqueue_ms_per_step": round(host_dt * 1e3, 3),
             "rccl_ranks": rccl_ranks,
-            "dp": None if world == 1 else {"exchange": ddp.reducer.exchange, "comm_dtype": ddp.reducer.comm_dtype,
+            "dp": None if world == 1 else {"backend": ddp.reducer.backend, "exchange": ddp.reducer.exchange, "comm_dtype": ddp.reducer.comm_dtype,
                                            "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
                                            "cus_left_to_rccl_during_backward": ddp._reserve,
                                            # exchange order = backward-completion order; MB of fp32 per bucket

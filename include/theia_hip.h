@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define THEIA_ABI_VERSION 8
+#define THEIA_ABI_VERSION 9
 
 enum { THEIA_OK = 0, THEIA_ERR_INVALID = -1, THEIA_ERR_LAUNCH = -2, THEIA_ERR_UNSUPPORTED = -3 };
 enum { THEIA_F32 = 0, THEIA_BF16 = 1,
@@ -376,6 +376,29 @@ int theia_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n
  * all-reduce (the optional bf16 exchange of theia_amd/parallel.py; replaces nothing in the reference, whose DDP exchanges fp32:
  * train_rvfm.py:258).  Both buffers 16-byte aligned. */
 int theia_upcast_scale_bf16(const void* src_bf16, float* dst, int64_t n, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Gradient exchange over RCCL / xGMI through the C ABI: what DistributedDataParallel's reducer does for the reference
+ * (scripts/train/train_rvfm.py:258 wraps the model, :125 backward() fires the bucket all-reduces; accelerate / torch.distributed
+ * "nccl" underneath).  One communicator per process = per GPU; the caller moves the 128-byte id from rank 0 to the other ranks
+ * out of band (a file, MPI, torch.distributed's store), exactly as with ncclGetUniqueId.  RCCL is bound when the first theia_comm_*
+ * function is called (dlopen "librccl.so.1": the copy already in the process if there is one); THEIA_ERR_UNSUPPORTED if it cannot
+ * be found.  Collectives are IN PLACE on `buf`, enqueued on `stream`, never synchronised; every rank must issue the same sequence.
+ * The engine fills flat gradient buckets in backward-completion order (theia_amd/engine.py), so the host side is one
+ * theia_comm_allreduce(bucket, average = 1) per finished bucket on a side stream (theia_amd/parallel.py, THEIA_DP_BACKEND=abi).
+ * ------------------------------------------------------------------------------------------------ */
+#define THEIA_COMM_ID_BYTES 128
+/* rank 0: id_host[0 .. THEIA_COMM_ID_BYTES) (HOST memory) = a fresh communicator id */
+int theia_comm_unique_id(void* id_host);
+/* all ranks, collectively, each with its GPU current (hipSetDevice): *comm_out = this rank's communicator */
+int theia_comm_init(void** comm_out, const void* id_host, int world, int rank);
+/* buf[0 .. count) = sum (average = 0) or mean (average != 0: RCCL's AVG, no scale kernel) over the ranks; dtype THEIA_F32 / THEIA_BF16 */
+int theia_comm_allreduce(void* comm, void* buf, int64_t count, int dtype, int average, void* stream);
+/* buf of rank `root` to every rank: the parameter broadcast DDP's constructor performs (train_rvfm.py:258) */
+int theia_comm_broadcast(void* comm, void* buf, int64_t count, int dtype, int root, void* stream);
+int theia_comm_size(void* comm, int* world, int* rank);
+/* collective; NULL is a no-op */
+int theia_comm_destroy(void* comm);
 
 /* Global-norm gradient clipping over flat f32 gradient ranges (nn.utils.clip_grad_norm_ at train_rvfm.py:126-130) without a host
  * round trip.  theia_grad_sumsq: partials[0 .. theia_grad_sumsq_blocks()) = partial sums of squares of g[0..n) (g 16-byte aligned;

@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/theia_hip.h but not exported"
     assert sorted(N.EXPORTED_SYMBOLS) == declared, "ctypes signature table and header disagree"
-    assert lib.theia_abi_version() == N.ABI_VERSION == 8
+    assert lib.theia_abi_version() == N.ABI_VERSION == 9
     assert lib.theia_dtype_size(N.F32) == 4 and lib.theia_dtype_size(N.BF16) == 2 and lib.theia_dtype_size(7) == -1
 
 
@@ -195,6 +195,14 @@ def test_argument_validation_errors_without_gpu():
     assert lib.theia_wgrad_splits(25216, 768, 768) >= 1
     with pytest.raises(N.TheiaNativeError):
         N.check(-1, "x")
+    # theia_comm_*: argument checks come before RCCL is looked for; a NULL communicator is a no-op to destroy
+    assert lib.theia_comm_allreduce(None, None, 0, N.F32, 1, None) == -1 and b"theia_comm_allreduce" in lib.theia_last_error()
+    assert lib.theia_comm_broadcast(None, 4096, 16, N.F32, 0, None) == -1
+    assert lib.theia_comm_allreduce(4096, 4096, 16, N.FP8, 1, None) == -1 and b"dtype" in lib.theia_last_error()
+    assert lib.theia_comm_unique_id(None) == -1 and lib.theia_comm_destroy(None) == 0
+    import ctypes
+    h = ctypes.c_void_p()
+    assert lib.theia_comm_init(ctypes.byref(h), b"\0" * N.COMM_ID_BYTES, 2, 2) == -1 and b"rank 2 of 2" in lib.theia_last_error()
 
 
 def test_convT_parity_classes_cover_output_exactly_once():

@@ -42,7 +42,7 @@ def rnd(x, dt):
 def test_library_loads_and_abi():
     from theia_amd import _native as N
     lib = N.lib()
-    assert lib.theia_abi_version() == N.ABI_VERSION == 8
+    assert lib.theia_abi_version() == N.ABI_VERSION == 9
     assert lib.theia_dtype_size(N.BF16) == 2
 
 

@@ -118,6 +118,64 @@ def test_bench_launches_itself_on_two_gpus():
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["value"] > 0 and line["config"]["global_batch"] == 32
 
 
+def test_abi_communicator_world_1():
+    """theia_comm_* (include/theia_hip.h) on the one GPU that is always there: RCCL is bound by dlopen (the copy torch.distributed already
+    loaded), a 1-rank communicator is built from a fresh id, and the in-place collectives run on the caller's stream -- mean and sum over
+    one rank and a broadcast from rank 0 leave the buffer bit-identical.  GradBucketReducer(backend="abi") routes a bucket through it, with
+    and without the bf16 wire.  (N > 1 ranks: test_dp2_abi_backend_matches_single_process_gradient, where >= 2 GPUs are visible.)"""
+    import ctypes
+
+    from theia_amd import _native as N
+    from theia_amd.parallel import AbiCommunicator, GradBucketReducer
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    comm = AbiCommunicator(device=dev)
+    assert comm.world == 1 and comm.rank == 0
+    w, r = ctypes.c_int(-1), ctypes.c_int(-1)
+    assert N.lib().theia_comm_size(comm._handle, ctypes.byref(w), ctypes.byref(r)) == 0 and (w.value, r.value) == (1, 0)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(1 << 20, generator=g).to(dev, dt)
+        want = x.clone()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # enqueued on the CURRENT stream
+            comm.allreduce(x, average=True)
+            comm.allreduce(x, average=False)
+            comm.broadcast(x, 0)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        assert torch.equal(x, want)
+    with pytest.raises(ValueError):
+        comm.allreduce(torch.zeros(4, device=dev, dtype=torch.float16))
+    for wire in ("fp32", "bf16"):
+        red = GradBucketReducer(backend="abi", comm_dtype=wire)
+        red._abi = comm
+        flat = torch.randn(4096, generator=g).to(dev)
+        want = flat.clone() if wire == "fp32" else flat.bfloat16().float()
+        work, post = red._reduce(flat, True)
+        assert work is None
+        if post is not None:
+            post()
+        assert torch.equal(flat, want)
+    comm.close()
+    comm.close()  # idempotent
+
+
+@two_gpus
+def test_dp2_abi_backend_matches_single_process_gradient():
+    """the data-parallel step with the gradient buckets exchanged by theia_comm_allreduce (THEIA_DP_BACKEND=abi) instead of torch.distributed"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    os.environ["THEIA_DP_BACKEND"] = "abi"
+    try:
+        mp.spawn(_worker, args=(2, _free_port(), ret, "nccl", "allreduce", "fp32"), nprocs=2, join=True)
+    finally:
+        os.environ.pop("THEIA_DP_BACKEND", None)
+    assert ret["n"] > 100
+    name, err = ret["worst"]
+    assert err < 2e-4, (name, err)
+
+
 @one_gpu_rig
 def test_dp2_on_one_gpu_matches_single_process_gradient():
     mgr = mp.Manager()

@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtheia_hip.so")
 
 F32, BF16, FP8 = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
+COMM_ID_BYTES = 128  # THEIA_COMM_ID_BYTES
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_MUL_DGELU, ACT_MUL_DRELU = 0, 1, 2, 3, 4
 MAX_TAPS = 9
 
@@ -132,6 +133,12 @@ _SIGNATURES = {
     "theia_adamw_step_scaled": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 7 + [C.c_void_p, C.c_void_p]),
     "theia_adamw_step_dev": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "theia_upcast_scale_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "theia_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "theia_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
+    "theia_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "theia_comm_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "theia_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "theia_comm_destroy": (C.c_int, [C.c_void_p]),
     "theia_grad_sumsq_blocks": (C.c_int, []),
     "theia_grad_sumsq": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "theia_grad_clip_coef": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

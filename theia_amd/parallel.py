@@ -55,6 +55,50 @@ def reserved_cus() -> int:
     return max(0, int(n)) if n else rccl_channels()
 
 
+class AbiCommunicator:
+    """``theia_comm_*`` of include/theia_hip.h: RCCL driven through the library's C ABI instead of ``torch.distributed`` -- the path a
+    non-PyTorch host would use.  Rank 0's 128-byte communicator id travels over the process group that already exists
+    for the rendezvous (its store); the collectives themselves are enqueued on the CURRENT stream, in place, and return nothing to wait
+    for (stream order is the synchronisation)."""
+
+    def __init__(self, process_group=None, device: Optional[torch.device] = None):
+        import ctypes
+
+        from . import _native as N
+        self._N = N
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        ident = ctypes.create_string_buffer(N.COMM_ID_BYTES)
+        if self.rank == 0:
+            N.check(N.lib().theia_comm_unique_id(ident), "theia_comm_unique_id")
+        box = [ident.raw if self.rank == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=process_group)
+        self._handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().theia_comm_init(ctypes.byref(self._handle), box[0], self.world, self.rank), "theia_comm_init")
+
+    def _args(self, t: torch.Tensor):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)):
+            raise ValueError("AbiCommunicator: contiguous f32 / bf16 device tensors only")
+        return self._handle, t.data_ptr(), t.numel(), self._N.dtype_code(t.dtype)
+
+    def allreduce(self, t: torch.Tensor, average: bool = True) -> None:
+        h, p, n, dt = self._args(t)
+        self._N.check(self._N.lib().theia_comm_allreduce(h, p, n, dt, int(average), self._N.stream_ptr()), "theia_comm_allreduce")
+
+    def broadcast(self, t: torch.Tensor, root: int = 0) -> None:
+        h, p, n, dt = self._args(t)
+        self._N.check(self._N.lib().theia_comm_broadcast(h, p, n, dt, root, self._N.stream_ptr()), "theia_comm_broadcast")
+
+    def close(self) -> None:
+        if self._handle:
+            torch.cuda.synchronize(self.device)
+            self._N.check(self._N.lib().theia_comm_destroy(self._handle), "theia_comm_destroy")
+            self._handle = None
+
+
 class GradBucketReducer:
     """Average flat gradient buckets across ranks, asynchronously, in the order they become ready.
 
@@ -64,10 +108,18 @@ class GradBucketReducer:
                 sharded optimizer step would use -- and the all-gather can trail the next bucket's reduce-scatter);
     comm_dtype: "fp32" (default) or "bf16" -- the bucket is rounded to bf16 for the exchange (half the bytes on the xGMI links: 376
                 instead of 752 MB per step for DeiT-base + 5 teachers) and widened back into the fp32 bucket afterwards.
-    Environment: THEIA_DP_EXCHANGE, THEIA_DP_COMM_DTYPE."""
+    backend:    "torch" (default) -- ``torch.distributed`` collectives on the process group (RCCL on GPUs, gloo in the CPU tests);
+                "abi" -- device buckets go through ``theia_comm_allreduce`` (``AbiCommunicator``; all-reduce exchange only), the
+                process group is used for the rendezvous alone.
+    Environment: THEIA_DP_EXCHANGE, THEIA_DP_COMM_DTYPE, THEIA_DP_BACKEND."""
 
-    def __init__(self, process_group=None, exchange: Optional[str] = None, comm_dtype: Optional[str] = None):
+    def __init__(self, process_group=None, exchange: Optional[str] = None, comm_dtype: Optional[str] = None,
+                 backend: Optional[str] = None):
         self.pg = process_group
+        self.backend = backend or os.environ.get("THEIA_DP_BACKEND", "torch")
+        if self.backend not in ("torch", "abi"):
+            raise ValueError(f"GradBucketReducer: backend={self.backend!r}")
+        self._abi: Optional[AbiCommunicator] = None
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.exchange = exchange or os.environ.get("THEIA_DP_EXCHANGE", "allreduce")
@@ -81,6 +133,13 @@ class GradBucketReducer:
     # ------------------------------------------------------------------ the exchange itself (on whatever stream is current)
     def _exchange(self, buf: torch.Tensor, avg: bool):
         """all-reduce `buf` (SUM or AVG) with the configured collective(s); returns the last work handle (or None)"""
+        if self.backend == "abi" and buf.is_cuda:
+            if self.exchange != "allreduce":
+                raise ValueError("GradBucketReducer: backend 'abi' exchanges with all-reduce only")
+            if self._abi is None:
+                self._abi = AbiCommunicator(self.pg, buf.device)
+            self._abi.allreduce(buf, average=avg)  # stream-ordered on the current (side) stream: nothing to wait for
+            return None
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         async_ok = avg or not buf.is_cuda or os.environ.get("THEIA_GLOO_ASYNC") == "1"
         if self.exchange == "rs_ag" and buf.numel() % self.world == 0:
@@ -126,7 +185,7 @@ class GradBucketReducer:
             return
         # RCCL has an AVG reduction (no extra scale kernel); gloo (CPU tests, and the 2-ranks-on-one-GPU test) sums and
         # the result is scaled when the bucket is waited for
-        avg = dist.get_backend(self.pg) == "nccl"
+        avg = dist.get_backend(self.pg) == "nccl" or (self.backend == "abi" and flat.is_cuda)
         if flat.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=flat.device)
