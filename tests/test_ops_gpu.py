@@ -33,6 +33,18 @@ def relerr(a, b):
 TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
 
 
+def elem_excess(out, ref, rel=2.0 ** -8):
+    """Elementwise criterion (relerr above is relative to the LARGEST entry, blind to the small ones): the largest amount by which an
+    entry's error exceeds `rel` times that entry's own magnitude.  A bf16 result computed with f32 accumulation is the correctly rounded
+    f32 value up to the accumulation-order noise, so this must stay at that noise (~1e-5 for O(1) data) however small the entry."""
+    out = out.double().cpu()
+    ref = ref.double().cpu()
+    return float(((out - ref).abs() - rel * ref.abs()).max())
+
+
+ELEM_FLOOR = 1e-4  # absolute: f32 accumulation-order differences + the bf16 GELU polynomial (3e-5), for O(1) operands
+
+
 def rnd(x, dt):
     """value after rounding to the compute dtype (as f32 CPU tensor)."""
     return x.to(dt).float()
@@ -130,16 +142,21 @@ def test_linear_bias_epilogues(dt, M, N, K, tile):
     xr, wr, rr = rnd(x, dt), rnd(w, dt), rnd(res, dt)
     ref = xr @ wr.t() + bias
     xd, wd, bd, rd = x.to(dev, dt), w.to(dev, dt), bias.to(dev), res.to(dev, dt)
+    bf = dt == torch.bfloat16  # bf16: every entry also within one bf16 rounding of ITS OWN magnitude (+ accumulation noise)
     y = linear(xd, wd, bd)
     assert relerr(y.float(), ref) < TOL[dt]
+    assert not bf or elem_excess(y, ref) < ELEM_FLOOR
     y = linear(xd, wd, bd, resid=rd)
     assert relerr(y.float(), ref + rr) < TOL[dt]
+    assert not bf or elem_excess(y, ref + rr) < ELEM_FLOOR
     pre = torch.empty(M, N, dtype=dt, device=dev)
     y = linear(xd, wd, bd, act=Nn.ACT_GELU, aux_out=pre)
     assert relerr(pre.float(), ref) < TOL[dt]
     assert relerr(y.float(), torch.nn.functional.gelu(ref)) < TOL[dt]
+    assert not bf or max(elem_excess(pre, ref), elem_excess(y, torch.nn.functional.gelu(ref.double()))) < ELEM_FLOOR
     y = linear(xd, wd, bd, act=Nn.ACT_RELU)
     assert relerr(y.float(), torch.relu(ref)) < TOL[dt]
+    assert not bf or elem_excess(y, torch.relu(ref)) < ELEM_FLOOR
     # backward-of-GELU epilogue
     aux = h((M, N), 5, 2.0)
     ar = rnd(aux, dt)
@@ -252,6 +269,8 @@ def test_conv_family_fwd_dgrad_wgrad(dt, kind, C, tile):
         ops.gemm_nt(xd, wf, out_relu, b * mpi, C, rmap.ntaps * C, rmap, 9 * C, C, bias=bias.to(dev), act=Nn.ACT_RELU, tile=tile)
     assert relerr(out.float(), ref.detach()) < TOL[dt]
     assert relerr(out_relu.float(), ref_relu.detach()) < TOL[dt]
+    if dt == torch.bfloat16:  # ... and every entry within one bf16 rounding of its own magnitude (small entries included)
+        assert max(elem_excess(out, ref.detach()), elem_excess(out_relu, ref_relu.detach())) < ELEM_FLOOR
     if tile == 256009 and not conv_kernel_dgrad:
         return
     # data gradient
@@ -260,6 +279,7 @@ def test_conv_family_fwd_dgrad_wgrad(dt, kind, C, tile):
     rmap, mpi = plan.dgrad
     ops.gemm_nt(gyd, wdg, dx, b * mpi, C, 9 * C, rmap, 9 * C, C, tile=tile)
     assert relerr(dx.float(), xr.grad) < TOL[dt]
+    assert dt != torch.bfloat16 or elem_excess(dx, xr.grad) < ELEM_FLOOR
     if tile != 0:
         return  # the weight-gradient kernels have no tile request: covered once
     # weight gradient: reduction over output pixels (all classes into one slab set, then one reduce) ...
