@@ -90,6 +90,7 @@ def parse(argv=None):
     ap.add_argument("--graph", action="store_true",
                     help="single GPU: run the step as ONE hipGraph replay (theia_amd/train_graph.py) instead of ~1500 eager launches")
     ap.add_argument("--no-selfcheck", action="store_true", help="tuning runs only: the printed line is marked unchecked")
+    ap.add_argument("--no-dp-autotune", action="store_true", help="N > 1: skip the start-up measurement of the CU reservation for RCCL")
     ap.add_argument("--no-optimizer", action="store_true", help="exclude the AdamW update from the step")
     return ap.parse_args(argv)
 
@@ -474,6 +475,11 @@ def main(argv=None):
             break
         prev3 = cur3
     log(f"settled after {settle_steps} extra untimed steps")
+    dp_tune = {}
+    if world > 1 and not args.no_dp_autotune:
+        # untimed: how many CUs to leave to RCCL during the gradient exchange, measured on this job's own step (parallel.py)
+        dp_tune = ddp.autotune_reserved_cus(step)
+        log(f"CU reservation for the gradient exchange: ms/step per candidate {dp_tune} -> {ddp._reserve} CUs")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -617,6 +623,7 @@ def main(argv=None):
             "dp": None if world == 1 else {"backend": ddp.reducer.backend, "exchange": ddp.reducer.exchange, "comm_dtype": ddp.reducer.comm_dtype,
                                            "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
                                            "cus_left_to_rccl_during_backward": ddp._reserve,
+                                           "reservation_autotune_ms_per_step": dp_tune or None,
                                            # exchange order = backward-completion order; MB of fp32 per bucket
                                            "buckets_mb": [[bk.name, round(bk.numel * 4 / 1e6, 1)] for bk in model.engine.buckets]},
             "selfcheck": checks if checks else "skipped (--no-selfcheck): unchecked run",

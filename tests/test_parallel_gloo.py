@@ -201,3 +201,15 @@ def test_cu_budget_is_restored_to_what_it_was_not_to_the_whole_device():
         assert state["cus"] == 200 and not ddp._callback_queued
     finally:
         ops.get_compute_cus, ops.set_compute_cus = orig
+
+
+def test_cu_reservation_choice_needs_a_clear_gain():
+    """TheiaDataParallel.autotune_reserved_cus times a step per candidate reservation; pick_reservation keeps the smallest candidate
+    (nothing reserved) unless another one is faster by more than the margin -- noise does not switch a reservation on -- and the
+    cheapest of equally fast ones otherwise."""
+    from theia_amd.parallel import pick_reservation
+    assert pick_reservation({0: 50.0, 16: 49.8, 32: 49.9, 64: 51.0}) == 0      # 0.4 %: noise
+    assert pick_reservation({0: 50.0, 16: 47.0, 32: 46.0, 64: 48.0}) == 32     # clear winner
+    assert pick_reservation({0: 50.0, 16: 46.0, 32: 46.0, 64: 48.0}) == 16     # tie: the smaller reservation
+    assert pick_reservation({0: 50.0}) == 0
+    assert pick_reservation({16: 50.0, 32: 45.0}, min_gain=0.05) == 32          # base = the smallest candidate offered

@@ -72,6 +72,15 @@ def _worker(rank, world, port, ret, backend="gloo", exchange="allreduce", comm_d
         (0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]).backward()
     torch.cuda.synchronize()
     got = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    if backend == "nccl":  # the start-up measurement of the CU reservation: collective, same decision on every rank
+
+        def one_step():
+            ls = model.get_loss(ddp(images[sl]), {t: v[sl].to(dev) for t, v in targets.items()}, as_float=False)
+            (0.9 * ls["cos_loss"] + 0.1 * ls["l1_loss"]).backward()
+
+        tune = ddp.autotune_reserved_cus(one_step, candidates=(0, 16), steps=1)
+        if rank == 0:
+            ret["tune"] = (sorted(tune), ddp._reserve)
     if rank == 0:
         params = O.synth_params(bb, teachers, 0)
         _, _, ref, _ = O.train_step_grads(params, images, targets, bb, teachers, "cos_l1")
@@ -101,6 +110,7 @@ def test_dp2_rccl_matches_single_process_gradient(exchange, comm_dtype):
     mp.spawn(_worker, args=(2, _free_port(), ret, "nccl", exchange, comm_dtype), nprocs=2, join=True)
     assert ret["backend"] == "nccl" and ret["world"] == 2
     assert ret["n"] > 100
+    assert ret["tune"][0] == [0, 16] and ret["tune"][1] in (0, 16)
     name, err = ret["worst"]
     assert err < (2e-4 if comm_dtype == "fp32" else 1e-2), (name, err)
 
@@ -159,6 +169,17 @@ def test_abi_communicator_world_1():
         assert torch.equal(flat, want)
     comm.close()
     comm.close()  # idempotent
+
+
+def test_reservation_autotune_is_a_noop_for_one_rank():
+    from theia_amd.foundation_models.common import get_model_feature_size
+    from theia_amd.models.rvfm import RobotVisionFM
+    from theia_amd.parallel import TheiaDataParallel
+    model = RobotVisionFM(backbone="facebook/deit-tiny-patch16-224", translator="lconv", translator_kwargs={"hidden_size_factor": 1.0},
+                          target_feature_sizes={"facebook/dinov2-large": get_model_feature_size("facebook/dinov2-large", keep_spatial=True)},
+                          precision="fp32").to("cuda:0")
+    calls = []
+    assert TheiaDataParallel(model).autotune_reserved_cus(lambda: calls.append(1)) == {} and not calls
 
 
 @two_gpus

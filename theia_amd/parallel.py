@@ -251,6 +251,15 @@ def broadcast_parameters(params, src: int = 0, process_group=None, bucket_bytes:
         flush()
 
 
+def pick_reservation(ms_per_step: dict, min_gain: float = 0.01) -> int:
+    """The CU reservation to keep after ``TheiaDataParallel.autotune_reserved_cus``: the fastest measured one, but the smallest candidate
+    (normally 0 = nothing reserved) unless another one beats it by more than ``min_gain`` (relative) -- run-to-run noise must not
+    switch a reservation on."""
+    base = min(ms_per_step)
+    best = min(ms_per_step, key=lambda r: (ms_per_step[r], r))
+    return best if ms_per_step[best] < ms_per_step[base] * (1.0 - min_gain) else base
+
+
 class TheiaDataParallel(torch.nn.Module):
     """``DDP``-shaped wrapper: exposes ``.module``, ``parameters()``, ``train()/eval()``, ``__call__``.
 
@@ -285,6 +294,38 @@ class TheiaDataParallel(torch.nn.Module):
         if self._saved_cus is not None:
             ops.set_compute_cus(self._saved_cus)
             self._saved_cus = None
+
+    def autotune_reserved_cus(self, step_fn: Callable[[], object], candidates=(0, 16, 32, 64), steps: int = 3,
+                              min_gain: float = 0.01) -> dict:
+        """Measure, at start-up, how many CUs the GEMM planners should leave to RCCL while gradient buckets are in flight, and keep the
+        best: ``step_fn()`` (one whole training step) is timed ``steps`` times per candidate (max over ranks), ``pick_reservation``
+        decides.  The persistent NT kernel and the weight-gradient kernel hold a whole CU per workgroup, so a collective that takes k CUs
+        pushes k workgroups of a 256-workgroup launch into a second round unless the planners were told (``theia_set_compute_cus``); how
+        many CUs RCCL actually takes depends on its version, the topology and the message size -- so it is measured on the job's own
+        step instead of guessed.  Collective: every rank calls it at the same point; all ranks reach the same decision (the timings
+        are reduced with MAX).  Returns {candidate: ms per step}; {} when there is nothing to tune (one rank, CPU / gloo, or the user
+        fixed the value with THEIA_DP_RESERVED_CUS / THEIA_RCCL_MAX_NCHANNELS)."""
+        import time
+        first = next(iter(self.module.parameters()), None)
+        if (self.reducer.world == 1 or first is None or not first.is_cuda or dist.get_backend(self.reducer.pg) != "nccl"
+                or os.environ.get("THEIA_DP_RESERVED_CUS") or os.environ.get("THEIA_RCCL_MAX_NCHANNELS")):
+            return {}
+        dev = first.device
+        results = {}
+        for r in candidates:
+            self._reserve = int(r)
+            step_fn()  # one untimed step under the new budget
+            torch.cuda.synchronize(dev)
+            dist.barrier(group=self.reducer.pg)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step_fn()
+            torch.cuda.synchronize(dev)
+            tt = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.reducer.pg)
+            results[int(r)] = float(tt.item())
+        self._reserve = pick_reservation(results, min_gain)
+        return results
 
     def _on_bucket(self, bucket, side_event=None) -> None:
         if not self._callback_queued:
