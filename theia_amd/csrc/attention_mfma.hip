@@ -27,6 +27,9 @@ __device__ __forceinline__ void am_mma(am_f32x4& acc, const uint4& a, const uint
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(am_bf16x8, a), __builtin_bit_cast(am_bf16x8, b), acc, 0, 0, 0);
 }
 
+// keep `a` or zeros (component-wise: `c ? a : zero` on two uint4 lvalues is an lvalue select, i.e. a pointer, and sends the arrays to scratch)
+__device__ __forceinline__ uint4 am_keep(bool c, const uint4& a) { return make_uint4(c ? a.x : 0u, c ? a.y : 0u, c ? a.z : 0u, c ? a.w : 0u); }
+
 // Stage two [token][64] bf16 matrices (ROWS_A / ROWS_B token rows, zero beyond n) with the given global row strides.  All of a
 // thread's 16-byte pieces of BOTH matrices are requested before the first is written to LDS: as a load -> wait -> store loop (what
 // the compiler makes of the obvious form) the staging was 13 exposed memory latencies per workgroup, most of the forward kernel.
@@ -34,28 +37,29 @@ template <int ROWS_A, int ROWS_B, int NT>
 __device__ __forceinline__ void am_stage2(const bf16_t* __restrict__ srcA, int64_t strideA, char* __restrict__ dstA,
                                           const bf16_t* __restrict__ srcB, int64_t strideB, char* __restrict__ dstB, int n) {
     constexpr int ITA = (ROWS_A * 8 + NT - 1) / NT, ITB = (ROWS_B * 8 + NT - 1) / NT;
+    // Every load is UNCONDITIONAL, from a row clamped to [0, n) (rows beyond n become zeros by a select behind the load): a load under a
+    // lane mask compiles to a branch, the compiler's wait-count bookkeeping turns conservative where the two sides meet
+    // (s_waitcnt vmcnt(0)), and the "all requests first" order above degenerated into one exposed latency per matrix and iteration.
     uint4 xa[ITA], xb[ITB];
 #pragma unroll
     for (int it = 0; it < ITA; ++it) {
-        const int v = threadIdx.x + it * NT, r = v >> 3, c = v & 7;
-        xa[it] = make_uint4(0, 0, 0, 0);
-        if (r < n && r < ROWS_A) xa[it] = *reinterpret_cast<const uint4*>(srcA + r * strideA + c * 8);
+        const int v = threadIdx.x + it * NT, r = min(v >> 3, n - 1), c = v & 7;
+        xa[it] = *reinterpret_cast<const uint4*>(srcA + r * strideA + c * 8);
     }
 #pragma unroll
     for (int it = 0; it < ITB; ++it) {
-        const int v = threadIdx.x + it * NT, r = v >> 3, c = v & 7;
-        xb[it] = make_uint4(0, 0, 0, 0);
-        if (r < n && r < ROWS_B) xb[it] = *reinterpret_cast<const uint4*>(srcB + r * strideB + c * 8);
+        const int v = threadIdx.x + it * NT, r = min(v >> 3, n - 1), c = v & 7;
+        xb[it] = *reinterpret_cast<const uint4*>(srcB + r * strideB + c * 8);
     }
 #pragma unroll
     for (int it = 0; it < ITA; ++it) {
         const int v = threadIdx.x + it * NT, r = v >> 3, c = v & 7;
-        if (r < ROWS_A) *reinterpret_cast<uint4*>(dstA + r * AM_PITCH + c * 16) = xa[it];
+        if ((ROWS_A * 8) % NT == 0 || r < ROWS_A) *reinterpret_cast<uint4*>(dstA + r * AM_PITCH + c * 16) = am_keep(r < n, xa[it]);
     }
 #pragma unroll
     for (int it = 0; it < ITB; ++it) {
         const int v = threadIdx.x + it * NT, r = v >> 3, c = v & 7;
-        if (r < ROWS_B) *reinterpret_cast<uint4*>(dstB + r * AM_PITCH + c * 16) = xb[it];
+        if ((ROWS_B * 8) % NT == 0 || r < ROWS_B) *reinterpret_cast<uint4*>(dstB + r * AM_PITCH + c * 16) = am_keep(r < n, xb[it]);
     }
 }
 
@@ -102,24 +106,34 @@ template <bool TAIL>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                             float* __restrict__ lse, int n, int h) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
-    char* sK = sm;                          // [208][144]
-    char* sV = sm + 208 * AM_PITCH;         // [224][144]
+    char* sK = sm;                          // [224][144] (rows 208 .. 223 are staged as zeros and never read: 224 * 8 pieces = 7 per thread,
+    char* sV = sm + AM_ROWS * AM_PITCH;     // [224][144]  no partial pass -- in a partial pass the compiler sinks the load behind the lane mask)
     const int bh = blockIdx.x, bi = bh / h, hi = bh % h;
     const int D = h * 64;
     const int64_t rs = 3 * (int64_t)D;
     const bf16_t* base = qkv + (int64_t)bi * n * rs + hi * 64;
-    am_stage2<208, AM_ROWS, 256>(base + D, rs, sK, base + 2 * D, rs, sV, n);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q16 = lane & 15, g = lane >> 4;
+    // The query fragments of a wave's NEXT tile are requested one tile ahead (the first one before K / V are staged): as a load at the
+    // top of each iteration the wave sat out one global-memory latency per query tile, 3-4 times per head.
+    // Unconditional loads from a clamped row (rows beyond n are zeroed at use): a load under a lane mask is a branch, and the compiler
+    // drains the memory counter where its two sides meet -- the latency would be paid on the spot after all.
+    uint4 qn[2];
+    auto q_request = [&](int qt) {
+        const int qrow = min(qt * 16 + q16, n - 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) qn[kk] = *reinterpret_cast<const uint4*>(base + qrow * rs + kk * 32 + g * 8);
+    };
+    q_request(wave);
+    am_stage2<AM_ROWS, AM_ROWS, 256>(base + D, rs, sK, base + 2 * D, rs, sV, n);
+    // a use in front of the barrier (free: the staging has just waited for every younger load) -- without it the compiler sinks the
+    // request to the fragments' first use behind the barrier, and the wave waits for it there
+    asm volatile("" ::"v"(qn[0].x), "v"(qn[0].y), "v"(qn[0].z), "v"(qn[0].w), "v"(qn[1].x), "v"(qn[1].y), "v"(qn[1].z), "v"(qn[1].w));
+    __syncthreads();
     for (int qt = wave; qt < AM_TILES; qt += 4) {
         const int qrow = qt * 16 + q16;
-        uint4 qf[2];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            qf[kk] = make_uint4(0, 0, 0, 0);
-            if (qrow < n) qf[kk] = *reinterpret_cast<const uint4*>(base + qrow * rs + kk * 32 + g * 8);
-        }
+        const uint4 qf[2] = {am_keep(qrow < n, qn[0]), am_keep(qrow < n, qn[1])};
+        q_request(qt + 4);
         am_f32x4 s[AM_TILES + 1];
         float mx = -INFINITY;
 #pragma unroll
@@ -525,7 +539,7 @@ static void am_set_lds(const void* kern, int bytes) {
 }
 
 int theia_attention_fwd_mfma(const void* qkv, void* o, float* lse, int b, int n, int h, hipStream_t s) {
-    const int lds = (208 + AM_ROWS) * AM_PITCH;
+    const int lds = 2 * AM_ROWS * AM_PITCH;
     am_set_lds(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<true>), lds);
     am_set_lds(reinterpret_cast<const void*>(attn_fwd_mfma_kernel<false>), lds);
     if (n > 192) hipLaunchKernelGGL(attn_fwd_mfma_kernel<true>, dim3(b * h), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, n, h);
