@@ -18,45 +18,56 @@ __global__ __launch_bounds__(256) void ln_row_fwd_kernel(const T* __restrict__ x
     const int lane = threadIdx.x & 63;
     const int nv = D >> 3;
     const float invD = 1.0f / (float)D;
+    // Every load is unconditional, from a vector index clamped into the row (lanes past the row mask their contribution with a select),
+    // and the row's x pieces AND the affine pieces are requested together at the top: under `if (vi < nv)` each piece was a branch with
+    // its own load -> s_waitcnt vmcnt(0) -> use (the compiler drains the memory counter where the sides of a branch meet), and the
+    // affine rows were fetched behind the statistics -- three exposed latencies per row for a wave that lives for one or two rows.
+    int vc[NV];
+    bool ok[NV];
+    float g8[NV][8], b8[NV][8];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = lane + 64 * i;
+        ok[i] = vi < nv;
+        vc[i] = ok[i] ? vi : nv - 1;
+    }
+    bool first = true;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * 4) {
         const T* xr = x + row * D;
         float v[NV][8];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) load8(xr + vc[i] * 8, v[i]);
+        if (first) {  // (wave-uniform; the affine pieces are the same for every row of the wave)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                load8(gamma + vc[i] * 8, g8[i]);
+                load8(beta + vc[i] * 8, b8[i]);
+            }
+            first = false;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the requests stay in front of the statistics (the scheduler moves loads down to their first use)
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int vi = lane + 64 * i;
-            if (vi < nv) {
-                load8(xr + vi * 8, v[i]);
+        for (int i = 0; i < NV; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += v[i][j];
-            }
-        }
+            for (int j = 0; j < 8; ++j) s += ok[i] ? v[i][j] : 0.f;
         const float mu = wave_sum(s) * invD;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int vi = lane + 64 * i;
-            if (vi < nv) {
+        for (int i = 0; i < NV; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float d = v[i][j] - mu;
-                    q += d * d;
-                }
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[i][j] - mu;
+                q += ok[i] ? d * d : 0.f;
             }
-        }
         const float var = wave_sum(q) * invD;
         const float rs = 1.0f / sqrtf(var + eps);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int vi = lane + 64 * i;
-            if (vi < nv) {
-                float g8[8], b8[8], o[8];
-                load8(gamma + vi * 8, g8);
-                load8(beta + vi * 8, b8);
+            float o[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * g8[j] + b8[j];
-                store8(y + row * D + vi * 8, o);
-            }
+            for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * g8[i][j] + b8[i][j];  // (outside the mask: a use under it would pull the loads in)
+            if (ok[i]) store8(y + row * D + vc[i] * 8, o);
         }
         if (lane == 0) {
             mean[row] = mu;
@@ -72,22 +83,25 @@ extern "C" int theia_layernorm_fwd(const void* x, const float* gamma, const floa
     int blocks = (int)((M + 3) / 4);
     if (blocks > 8192) blocks = 8192;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const bool small = D <= 1024;
+    // 8-element vectors per lane: 1 for D <= 512 (DeiT-small / -tiny: a second, fully masked vector would still be loaded -- the loads are
+    // unconditional), 2 for D <= 1024, else LN_MAXV
+    const int nvl = D <= 512 ? 1 : D <= 1024 ? 2 : LN_MAXV;
+#define LN_FWD_LAUNCH(TT, NVV)                                                                                                            \
+    hipLaunchKernelGGL((ln_row_fwd_kernel<TT, NVV>), dim3(blocks), dim3(256), 0, s, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, M, D, eps)
     if (dtype == THEIA_BF16) {
-        if (small) hipLaunchKernelGGL((ln_row_fwd_kernel<bf16_t, 2>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
-        else hipLaunchKernelGGL((ln_row_fwd_kernel<bf16_t, LN_MAXV>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
+        if (nvl == 1) LN_FWD_LAUNCH(bf16_t, 1); else if (nvl == 2) LN_FWD_LAUNCH(bf16_t, 2); else LN_FWD_LAUNCH(bf16_t, LN_MAXV);
     } else if (dtype == THEIA_F32) {
-        if (small) hipLaunchKernelGGL((ln_row_fwd_kernel<float, 2>), dim3(blocks), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps);
-        else hipLaunchKernelGGL((ln_row_fwd_kernel<float, LN_MAXV>), dim3(blocks), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps);
+        if (nvl == 1) LN_FWD_LAUNCH(float, 1); else if (nvl == 2) LN_FWD_LAUNCH(float, 2); else LN_FWD_LAUNCH(float, LN_MAXV);
     } else
         THEIA_CHECK_ARG(false, "theia_layernorm_fwd: bad dtype %d", dtype);
+#undef LN_FWD_LAUNCH
     THEIA_CHECK_LAUNCH("theia_layernorm_fwd");
     return THEIA_OK;
 }
 
 // backward: dx per row (wave); dgamma/dbeta accumulated per lane over the rows this wave visits, then
 // block-reduced through LDS and written as one partial row per block; a second kernel sums the partials.
-template <typename T, int NV>
+template <typename T, int NV, bool HAS_RES>
 __global__ __launch_bounds__(256) void ln_row_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const T* __restrict__ dres,
@@ -96,51 +110,58 @@ __global__ __launch_bounds__(256) void ln_row_bwd_kernel(const T* __restrict__ d
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 3;
     const float invD = 1.0f / (float)D;
+    // (unconditional loads from a clamped vector index, all of a row's pieces requested together: see ln_row_fwd_kernel)
+    int vc[NV];
+    bool ok[NV];
     float ag[NV][8], ab[NV][8], g8[NV][8];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int vi = lane + 64 * i;
+        ok[i] = vi < nv;
+        vc[i] = ok[i] ? vi : nv - 1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ag[i][j] = ab[i][j] = g8[i][j] = 0.f;
-        if (vi < nv) load8(gamma + vi * 8, g8[i]);
+        for (int j = 0; j < 8; ++j) ag[i][j] = ab[i][j] = 0.f;
+        load8(gamma + vc[i] * 8, g8[i]);
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+        float xv[NV][8], dv[NV][8], rr[HAS_RES ? NV : 1][8];  // rr: the residual-stream gradient, requested with the row (not after the
+#pragma unroll                                                   // reduction: a second exposed memory latency per row)
+        for (int i = 0; i < NV; ++i) {
+            load8(x + row * D + vc[i] * 8, xv[i]);
+            load8(dy + row * D + vc[i] * 8, dv[i]);
+            if constexpr (HAS_RES) load8(dres + row * D + vc[i] * 8, rr[i]);
+        }
         const float mu = mean[row], rs = rstd[row];
-        float xh[NV][8], gy[NV][8], rr[NV][8];  // rr: the residual-stream gradient, requested with the row (not after the
-        float s1 = 0.f, s2 = 0.f;                 // reduction: a second exposed memory latency per row)
+        __builtin_amdgcn_sched_barrier(0);  // every request of the row in front of the arithmetic
+        float xh[NV][8], gy[NV][8];
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int vi = lane + 64 * i;
-            if (vi < nv) {
-                float xv[8], dv[8];
-                load8(x + row * D + vi * 8, xv);
-                load8(dy + row * D + vi * 8, dv);
-                if (dres != nullptr) load8(dres + row * D + vi * 8, rr[i]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    xh[i][j] = (xv[j] - mu) * rs;
-                    gy[i][j] = dv[j] * g8[i][j];
-                    s1 += gy[i][j];
-                    s2 += gy[i][j] * xh[i][j];
-                    ag[i][j] += dv[j] * xh[i][j];
-                    ab[i][j] += dv[j];
-                }
+            for (int j = 0; j < 8; ++j) {
+                xh[i][j] = (xv[i][j] - mu) * rs;
+                gy[i][j] = dv[i][j] * g8[i][j];
+                s1 += ok[i] ? gy[i][j] : 0.f;
+                s2 += ok[i] ? gy[i][j] * xh[i][j] : 0.f;
+                ag[i][j] += ok[i] ? dv[i][j] * xh[i][j] : 0.f;
+                ab[i][j] += ok[i] ? dv[i][j] : 0.f;
             }
         }
         const float m1 = wave_sum(s1) * invD, m2 = wave_sum(s2) * invD;
+        if constexpr (HAS_RES) {  // a use outside the store mask (the data arrived long ago): otherwise the compiler sinks a piece's request into
+#pragma unroll                    // the masked block that is its only user, and the wave waits for it there
+            for (int i = 0; i < NV; ++i) asm volatile("" ::"v"(rr[i][0]));
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int vi = lane + 64 * i;
-            if (vi < nv) {
-                float o[8];
+            float o[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = rs * (gy[i][j] - m1 - xh[i][j] * m2);
-                if (dres != nullptr) {
+            for (int j = 0; j < 8; ++j) o[j] = rs * (gy[i][j] - m1 - xh[i][j] * m2);
+            if constexpr (HAS_RES) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] += rr[i][j];
-                }
-                store8(dx + row * D + vi * 8, o);
+                for (int j = 0; j < 8; ++j) o[j] += rr[i][j];
             }
+            if (ok[i]) store8(dx + row * D + vc[i] * 8, o);
         }
     }
     float* mine = red + wave * 2 * D;
@@ -204,15 +225,25 @@ extern "C" int theia_layernorm_bwd(const void* dy, const void* x, const float* g
     const int blocks = ln_bwd_blocks(M);
     const size_t lds = 4 * 2 * D * sizeof(float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const bool small = D <= 1024;
+    const bool res = dresid != nullptr;
+    const int nvl = D <= 512 ? 1 : D <= 1024 ? 2 : LN_MAXV;  // (see theia_layernorm_fwd)
+#define LN_BWD_LAUNCH(TT, NVV, RR)                                                                                                      \
+    hipLaunchKernelGGL((ln_row_bwd_kernel<TT, NVV, RR>), dim3(blocks), dim3(256), lds, s, (const TT*)dy, (const TT*)x, gamma, mean, rstd, \
+                       (const TT*)dresid, (TT*)dx, workspace, M, D)
+#define LN_BWD_NV(TT, RR)                                                     \
+    do {                                                                      \
+        if (nvl == 1) LN_BWD_LAUNCH(TT, 1, RR);                               \
+        else if (nvl == 2) LN_BWD_LAUNCH(TT, 2, RR);                          \
+        else LN_BWD_LAUNCH(TT, LN_MAXV, RR);                                  \
+    } while (0)
     if (dtype == THEIA_BF16) {
-        if (small) hipLaunchKernelGGL((ln_row_bwd_kernel<bf16_t, 2>), dim3(blocks), dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dresid, (bf16_t*)dx, workspace, M, D);
-        else hipLaunchKernelGGL((ln_row_bwd_kernel<bf16_t, LN_MAXV>), dim3(blocks), dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dresid, (bf16_t*)dx, workspace, M, D);
+        if (res) LN_BWD_NV(bf16_t, true); else LN_BWD_NV(bf16_t, false);
     } else if (dtype == THEIA_F32) {
-        if (small) hipLaunchKernelGGL((ln_row_bwd_kernel<float, 2>), dim3(blocks), dim3(256), lds, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dresid, (float*)dx, workspace, M, D);
-        else hipLaunchKernelGGL((ln_row_bwd_kernel<float, LN_MAXV>), dim3(blocks), dim3(256), lds, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dresid, (float*)dx, workspace, M, D);
+        if (res) LN_BWD_NV(float, true); else LN_BWD_NV(float, false);
     } else
         THEIA_CHECK_ARG(false, "theia_layernorm_bwd: bad dtype %d", dtype);
+#undef LN_BWD_NV
+#undef LN_BWD_LAUNCH
     THEIA_CHECK_LAUNCH("theia_layernorm_bwd");
     hipLaunchKernelGGL(partial_reduce_kernel<16>, dim3((2 * D + 15) / 16), dim3(256), 0, s, workspace, blocks, 2 * D,
                        (int64_t)2 * D, dgamma, dbeta, D, accumulate);
