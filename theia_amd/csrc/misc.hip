@@ -657,8 +657,20 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    if (c < N)
-        for (int p = pl; p < nparts; p += 4) s += part[(int64_t)p * N + c];
+    if (c < N) {
+        // 8 partial rows per pass, requested together (clamped row; rows past the end add 0; same order of additions): as a load -> add loop
+        // this was one L2 latency per partial row
+        for (int p0 = pl; p0 < nparts; p0 += 4 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = p0 + 4 * u;
+                v[u] = part[(int64_t)(p < nparts ? p : nparts - 1) * N + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += p0 + 4 * u < nparts ? v[u] : 0.f;
+        }
+    }
     red[pl][cl] = s;
     __syncthreads();
     if (pl == 0 && c < N) {
@@ -734,9 +746,21 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     double mse = 0.0, l1 = 0.0, cosl = 0.0;
     for (int s = threadIdx.x; s < b; s += 256) {
         double a[5] = {0, 0, 0, 0, 0};
-        for (int c = 0; c < nchunks; ++c)
+        // 4 chunks (20 floats) per pass requested together (clamped chunk; chunks past the end add 0; same order of additions): one L2
+        // latency per chunk before -- 128 in a row for the 64 x 64 teacher map
+        for (int c0 = 0; c0 < nchunks; c0 += 4) {
+            float v[4][5];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) a[k] += (double)part[((int64_t)s * nchunks + c) * 5 + k];
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u < nchunks ? c0 + u : nchunks - 1;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) v[u][k] = part[((int64_t)s * nchunks + c) * 5 + k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) a[k] += c0 + u < nchunks ? (double)v[u][k] : 0.0;
+        }
         mse += a[0];
         l1 += a[1];
         const double np = fmax(sqrt(a[3]), 1e-12), nq = fmax(sqrt(a[4]), 1e-12);  // F.normalize eps
