@@ -83,3 +83,41 @@ def test_gemm_and_attention_kernels_do_not_spill(tmp_path):
     # the attention backward kernels rely on 4 waves per SIMD (two 8-wave workgroups per CU): <= 128 registers
     bwd = [v for f, n, _s, v in rows if f == "attention_mfma.hip" and "bwd" in n]
     assert bwd and all(v <= 128 for v in bwd), bwd
+
+
+def _loads_before_first_wait(text, symbol_re):
+    """global loads issued by the kernel whose mangled name matches `symbol_re` before its first s_waitcnt on the vector-memory counter"""
+    lines = text.split("\n")
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\d+" + symbol_re + r"\S*:", l)]
+    assert starts, symbol_re
+    n = 0
+    for l in lines[starts[0]:]:
+        if "s_waitcnt" in l and "vmcnt" in l:
+            return n
+        if re.search(r"\bglobal_load_dword", l):
+            n += 1
+        if "s_endpgm" in l:
+            break
+    return n
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_latency_bound_kernels_request_their_loads_together(tmp_path):
+    """Round 4: a load under a lane mask compiles to a branch, and where the two sides meet the compiler drains the memory counter
+    (s_waitcnt vmcnt(0)) -- `if (row < n) x = load(...)` turned the "request everything, then use it" staging of the attention forward and
+    of the row LayerNorm kernels into one exposed memory latency per piece (attention forward 47 -> 42.5 us, row LayerNorm forward -12...-18 %
+    once the loads were unconditional from clamped addresses; profiles/r04_attention_fwd_prefetch.txt,
+    r04_row_layernorm_unconditional_loads.txt).  Nothing numerical notices a regression here, so the assembly is checked: these kernels
+    must issue all of a tile's / row's loads before the first wait on the memory counter."""
+    out = {}
+    for f in ("attention_mfma.hip", "norm.hip"):
+        o = os.path.join(str(tmp_path), f + ".s")
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", os.path.join(CSRC, f), "-o", o],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        out[f] = open(o).read()
+    # attention forward: 2 query fragments + 7 + 7 staging pieces of K and V
+    assert _loads_before_first_wait(out["attention_mfma.hip"], r"attn_fwd_mfma_kernelILb1") >= 16
+    # row LayerNorm forward, D = 768 (2 vectors per lane): 2 x pieces + gamma / beta (f32: two 16-byte loads per vector each)
+    assert _loads_before_first_wait(out["norm.hip"], r"ln_row_fwd_kernelItLi2") >= 10
+    # row LayerNorm backward with the residual-stream gradient: gamma (4) in front of the loop; inside it x, dy, residual per vector + the row's statistics
+    assert _loads_before_first_wait(out["norm.hip"], r"ln_row_bwd_kernelItLi2ELb1") >= 10
