@@ -713,6 +713,36 @@ extern "C" int theia_wgrad_reduce(const float* slabs, int splits, int N, int ksl
 //   (stride 9: Conv2d, and ConvTranspose2d reduced over input pixels) or by n (stride 9: ConvTranspose2d stride 1), and c itself
 //   for nn.Linear.  The plain wgrad_reduce_kernel wrote conv gradients with a 36-byte stride: 83 us for 85 MB (1 TB/s).
 // ------------------------------------------------------------------------------------------------
+// Sums over the split slabs, 8 slabs per pass requested together (a clamped slab index; slabs past the end add 0): as a load -> add loop a
+// thread paid one L2 latency per slab -- with the 64 splits of DeiT-tiny's one-tile weight gradients the finish kernels took 17-48 us for
+// a few MB.  The additions happen in the same order as before (k ascending).
+__device__ __forceinline__ float4 wf_sum4(const float* __restrict__ p, int64_t stride, int k0, int splits, float4 s) {
+    for (int k = k0; k < splits; k += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (int64_t)(k + u < splits ? k + u : splits - 1) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool in = k + u < splits;
+            s.x += in ? v[u].x : 0.f;
+            s.y += in ? v[u].y : 0.f;
+            s.z += in ? v[u].z : 0.f;
+            s.w += in ? v[u].w : 0.f;
+        }
+    }
+    return s;
+}
+__device__ __forceinline__ float wf_sum1(const float* __restrict__ p, int64_t stride, int k0, int splits, float s) {
+    for (int k = k0; k < splits; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u < splits ? k + u : splits - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += k + u < splits ? v[u] : 0.f;
+    }
+    return s;
+}
+
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ slabs, int splits, int N, int kslots, int C,
                                                            float* __restrict__ out, int64_t sn, int64_t ss, int64_t sc, int accumulate,
                                                            int TN, int TC, int wtiles, const float* __restrict__ bias_part,
@@ -721,8 +751,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
     if ((int)blockIdx.x >= wtiles) {  // bias blocks: out[n] (+)= sum_s part[s*N + n], fixed order
         const int n = ((int)blockIdx.x - wtiles) * 256 + threadIdx.x;
         if (n < N) {
-            float s = 0.f;
-            for (int q = 0; q < splits; ++q) s += bias_part[(int64_t)q * N + n];
+            const float s = wf_sum1(bias_part + n, N, 0, splits, 0.f);
             bias_out[n] = bias_accumulate ? bias_out[n] + s : s;
         }
         return;
@@ -744,10 +773,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             if (n0 + nn < N && c0 + cc < C) {
                 const int64_t idx = (int64_t)(n0 + nn) * krow + (int64_t)slot * C + c0 + cc;
-                for (int k = 0; k < splits; ++k) {
-                    const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)k * total + idx);
-                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-                }
+                s = wf_sum4(slabs + idx, total, 0, splits, s);
             }
             float* d = lds + (nn * kslots + slot) * pitch + cc;
             d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w;
@@ -760,7 +786,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
             float s = 0.f;
             if (n0 + nn < N && c0 + cc < C) {
                 const int64_t idx = (int64_t)(n0 + nn) * krow + (int64_t)slot * C + c0 + cc;
-                for (int k = 0; k < splits; ++k) s += slabs[(int64_t)k * total + idx];
+                s = wf_sum1(slabs + idx, total, 0, splits, s);
             }
             lds[(nn * kslots + slot) * pitch + cc] = s;
         }
@@ -789,8 +815,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_rows_kernel(const float* __r
     if ((int)blockIdx.x >= wblocks) {
         const int n = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
         if (n < N) {
-            float s = 0.f;
-            for (int q = 0; q < splits; ++q) s += bias_part[(int64_t)q * N + n];
+            const float s = wf_sum1(bias_part + n, N, 0, splits, 0.f);
             bias_out[n] = bias_accumulate ? bias_out[n] + s : s;
         }
         return;
@@ -800,10 +825,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_rows_kernel(const float* __r
     const float rcp = 1.0f / (float)c4n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)wblocks * 256) {
         float4 s = *reinterpret_cast<const float4*>(slabs + i * 4);
-        for (int k = 1; k < splits; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(slabs + (int64_t)k * total + i * 4);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
+        s = wf_sum4(slabs + i * 4, total, 1, splits, s);
         int c4;
         const int n = gt_divmod((int)i, c4n, rcp, c4);
         float4* d = reinterpret_cast<float4*>(out + (int64_t)n * sn + c4 * 4);
