@@ -37,7 +37,8 @@ rccl_api_t& rccl() {
             if (api.handle != nullptr) break;
         }
         if (api.handle == nullptr) {
-            snprintf(api.why, sizeof(api.why), "RCCL not found (%s)", dlerror());
+            const char* e = dlerror();
+            snprintf(api.why, sizeof(api.why), "RCCL not found (%s)", e != nullptr ? e : "dlopen failed");
             return;
         }
         auto sym = [&](const char* s) {
