@@ -94,7 +94,8 @@ def _worker_async_order(rank, world, port, ret, exchange="allreduce", comm_dtype
     sys.path.insert(0, ROOT)
     from theia_amd.parallel import GradBucketReducer, broadcast_parameters
     red = GradBucketReducer(exchange=exchange, comm_dtype=comm_dtype)
-    # bucket sizes: multiples of 8 like the engine's (divisible by the world size), one that is not (falls back to one all-reduce)
+    # bucket sizes: multiples of 8 like the engine's (divisible by the world size), and one that is not (rs_ag: exchanged through a
+    # zero-padded staging buffer with the same shard boundaries on every rank -- it used to fall back to an all-reduce silently)
     flats = [torch.full((1000 + 8 * i,), float(rank + 1) * (i + 1)) for i in range(5)] + [torch.full((1001,), float(rank + 1))]
     flats[2][7] = 0.1 * (rank + 1) + 3.0  # a value bf16 cannot hold exactly: the bf16 exchange rounds, the fp32 one must not
     for f in flats:
@@ -109,6 +110,11 @@ def _worker_async_order(rank, world, port, ret, exchange="allreduce", comm_dtype
     else:
         ok = ok and float(flats[2][7]) != 3.15 and abs(float(flats[2][7]) - 3.15) < 0.02  # went through bf16
     red.finish()  # idempotent
+    if exchange == "rs_ag":  # the odd-length bucket took the padded reduce-scatter + all-gather path, the others ran in place
+        ok = ok and len(red._pad) == 1 and next(iter(red._pad.values())).numel() == 1002
+    else:
+        ok = ok and len(red._pad) == 0
+    red.close()  # (no C-ABI communicator on gloo: a no-op, idempotent)
     # coalesced parameter broadcast: mixed shapes / dtypes, more bytes than one flat buffer
     torch.manual_seed(7 + rank)
     ps = [torch.randn(33, 5), torch.randn(7), torch.randn(4, 4, 4).double(), torch.randn(1000), torch.randn(3)]

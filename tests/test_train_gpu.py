@@ -366,3 +366,102 @@ def test_capturable_optimizer_used_eagerly_matches_the_plain_one():
     assert oa.step_count == ob.step_count == 3
     for (k, pa), (_k, pb) in zip(ma.named_parameters(), mb.named_parameters()):
         assert torch.equal(pa, pb), k
+
+
+def test_recapture_after_an_eval_forward_still_captures_the_operand_rebuild():
+    """Round-4 advisor finding: `StudentEngine._operands()` returned early when its cache was fresh, so a (re)capture taken right after an
+    eager eval forward (train_rvfm.py: `set_grad_clip()` voids the graph at steps == warmup_steps and `invalidate()` follows
+    `freeze_translator` -- both land on an epoch boundary, where the epoch-end eval runs between the void and the re-capture) recorded
+    NO operand rebuild: every later replay ran forward / backward on frozen bf16 weight copies while AdamW kept updating the masters.
+    Here: warm-up, capture, 2 replays, an eval forward, invalidate(), re-capture, 4 more replays -- bit-identical to the eager loop at
+    every step (a frozen operand cache shows from the second replay after the re-capture on)."""
+    from theia_amd.optimizers import FusedAdamW
+    from theia_amd.train_graph import CapturedTrainStep, default_main_loss
+    ma, teachers = _build("bf16")
+    mb, _ = _build("bf16")
+    oa, ob = FusedAdamW(ma, lr=2e-3, weight_decay=0.01), FusedAdamW(mb, lr=2e-3, weight_decay=0.01)
+    step_b = CapturedTrainStep(mb, ob, grad_clip=0.5, warmup=1)
+    B = 4
+    for i in range(8):
+        images = O.synth_images(B, i).to("cuda:0")
+        targets = {t: v.to("cuda:0") for t, v in O.synth_targets(B, teachers, 50 + i).items()}
+        if i == 3:  # the epoch boundary: eval forward on both models (refreshes the operand cache eagerly), then the void
+            with torch.no_grad():
+                assert torch.equal(ma.forward_feature(images), mb.forward_feature(images))
+            step_b.invalidate()
+        if i == 5:  # and the other trigger: a new clip threshold (re-capture with a fresh cache again)
+            with torch.no_grad():
+                mb.forward_feature(images)
+                ma.forward_feature(images)
+            step_b.set_grad_clip(0.25)
+        clip = 0.5 if i < 5 else 0.25
+        oa.zero_grad(set_to_none=True)
+        la = ma.get_loss(ma(images), targets, as_float=False)
+        main_a = default_main_loss(la)
+        main_a.backward()
+        oa.clip_grad_norm_(clip)
+        oa.step()
+        out = step_b(images, targets)
+        assert float(out["main_loss"]) == float(main_a), (i, float(out["main_loss"]), float(main_a))
+        for (ka, pa), (_kb, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert torch.equal(pa, pb), (i, ka)
+    assert step_b.replays == 7
+
+
+def test_capturing_an_unprepared_optimizer_step_is_refused():
+    """FusedAdamW in capturable mode reads lr / bias corrections from the device: a step() recorded into a stream capture without
+    prepare_step() would bake in whatever the scalars held -- it raises instead (CapturedTrainStep prepares before every replay)."""
+    from theia_amd.optimizers import FusedAdamW
+    m, teachers = _build("bf16")
+    o = FusedAdamW(m, lr=1e-3)
+    o.enable_capturable()
+    assert [float(v) for v in o._hyper] == [0.0, 1.0, 1.0]  # "no step yet" never divides by zero
+    images = O.synth_images(2, 0).to("cuda:0")
+    targets = {t: v.to("cuda:0") for t, v in O.synth_targets(2, teachers, 1).items()}
+    losses = m.get_loss(m(images), targets, as_float=False)
+    (0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]).backward()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="prepare_step"):
+        with torch.cuda.graph(g, stream=s):
+            o.step()
+    torch.cuda.synchronize()
+
+
+def test_optimizer_checkpoint_is_validated_and_remapped_by_parameter_name():
+    """FusedAdamW.state_dict() stores per-bucket flat moments.  A checkpoint written under another bucket layout (round 3: 4 ViT buckets,
+    round 4: 6) used to load its first buckets and then fail half-way; now nothing is copied before the layout checks out: same sizes ->
+    positional; different sizes + a stored layout -> re-mapped by parameter name; different sizes and no layout -> refused up front."""
+    from theia_amd.optimizers import FusedAdamW
+    m, teachers = _build("bf16")
+    o = FusedAdamW(m, lr=1e-3)
+    for st in o.flat_state:
+        st["m"].uniform_(-1, 1)
+        st["v"].uniform_(0, 1)
+    o.step_count = 7
+    sd = o.state_dict()
+    assert sd["layout_version"] == 2 and len(sd["layout"]) == len(o.flat_state)
+    # the same content under a different bucket layout: the last two buckets merged into one
+    merged = dict(sd)
+    merged["m"] = sd["m"][:-2] + [torch.cat(sd["m"][-2:])]
+    merged["v"] = sd["v"][:-2] + [torch.cat(sd["v"][-2:])]
+    shift = int(sd["m"][-2].numel())
+    merged["layout"] = sd["layout"][:-2] + [list(sd["layout"][-2]) + [(n, off + shift, k) for n, off, k in sd["layout"][-1]]]
+    m2, _ = _build("bf16")
+    o2 = FusedAdamW(m2, lr=1e-3)
+    o2.load_state_dict(merged)
+    assert o2.step_count == 7
+    names = {id(p): n for n, p in m2.named_parameters()}
+    for b, s_new, s_old in zip(m2.engine.buckets, o2.flat_state, o.flat_state):
+        for p, off in zip(b.params, b.offsets):  # (padding between parameters is never read by the update kernel's consumers)
+            assert torch.equal(s_new["m"][off:off + p.numel()], s_old["m"][off:off + p.numel()]), names[id(p)]
+            assert torch.equal(s_new["v"][off:off + p.numel()], s_old["v"][off:off + p.numel()]), names[id(p)]
+    # no layout and other sizes: refused before anything is touched
+    bad = {k: v for k, v in merged.items() if k not in ("layout", "layout_version")}
+    before = [st["m"].clone() for st in o2.flat_state]
+    with pytest.raises(ValueError, match="no layout"):
+        o2.load_state_dict(bad)
+    assert all(torch.equal(a, st["m"]) for a, st in zip(before, o2.flat_state)) and o2.step_count == 7
+    o2.load_state_dict(sd)  # and the positional path
+    assert all(torch.equal(a["m"], b["m"]) for a, b in zip(o.flat_state, o2.flat_state))

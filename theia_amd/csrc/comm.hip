@@ -6,7 +6,29 @@
 // on the caller's stream, never synchronised here.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// A ROCm install without the RCCL development headers still builds the library (RCCL is bound by dlopen at run time; without it the
+// theia_comm_* entries return THEIA_ERR_UNSUPPORTED).  The six entry points and the few types they use, as NCCL 2.x / RCCL define them:
+#define NCCL_UNIQUE_ID_BYTES 128
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3, ncclAvg = 4 } ncclRedOp_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7,
+               ncclFloat64 = 8, ncclBfloat16 = 9 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm,
+                           hipStream_t stream);
+ncclResult_t ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, int root, ncclComm_t comm,
+                           hipStream_t stream);
+const char* ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include <mutex>
 

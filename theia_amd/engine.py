@@ -448,7 +448,11 @@ class StudentEngine:
         params = self.all_params()
         ptr_key = (device, self.dtype) + tuple((p.data_ptr(), tuple(p.shape)) for p in params)
         key = (PARAM_EPOCH[0],) + tuple(p._version for p in params)
-        if ptr_key == self._op_ptr_key and key == self._opkey:
+        # A stream capture ALWAYS records the rebuild: a captured train step replays "rebuild, forward, backward, update", and if the
+        # cache happened to be fresh at capture time (an eval forward between the last optimizer step and a re-capture) the replays
+        # would run on frozen operand copies while AdamW keeps updating the masters (round-4 advisor finding)
+        capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if ptr_key == self._op_ptr_key and key == self._opkey and not capturing:
             return self._opcache
         if ptr_key != self._op_ptr_key:
             self._opcache, self._opbatch = self._build_operand_table(device)

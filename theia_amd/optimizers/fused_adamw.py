@@ -120,6 +120,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._hyper is None:
             dev = self.flat_state[0]["p"].device
             self._hyper = torch.zeros(3, dtype=torch.float32, device=dev)
+            self._hyper[1:3].fill_(1.0)  # bias corrections of "no step yet": never a division by zero
         self.capturable = True
 
     @torch.no_grad()
@@ -146,7 +147,11 @@ class FusedAdamW(torch.optim.Optimizer):
         if self.capturable:  # the per-step scalars come from the device
             # an eager step() of a capturable optimizer without prepare_step() (e.g. user code between two captured phases) refreshes
             # them itself; inside a capture they must already be in place (CapturedTrainStep calls prepare_step before every replay)
-            if not getattr(self, "_prepared", False) and not torch.cuda.is_current_stream_capturing():
+            if not getattr(self, "_prepared", False):
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("FusedAdamW.step() inside a stream capture without prepare_step(): the captured update would "
+                                       "bake in stale device scalars (learning rate / bias corrections) -- call prepare_step() before "
+                                       "the capture and before every replay (CapturedTrainStep does)")
                 self.prepare_step()
             self._prepared = False
             for b, st, s, e, decay in self._live_runs():
@@ -165,14 +170,43 @@ class FusedAdamW(torch.optim.Optimizer):
         return loss
 
     # checkpointing: flat moments + step counter (the per-parameter ``state`` dict of torch optimizers is not used)
+    def _layout(self):
+        """[[(parameter name, offset in the bucket's flat buffer, numel)]] per bucket -- what a checkpoint's moments are matched against"""
+        return [[(n, int(o), int(p.numel())) for n, o, p in zip(b.names, b.offsets, b.params)] for b in self.engine.buckets]
+
     def state_dict(self):
         return {"step_count": self.step_count, "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
-                "m": [st["m"].clone() for st in self.flat_state], "v": [st["v"].clone() for st in self.flat_state]}
+                "m": [st["m"].clone() for st in self.flat_state], "v": [st["v"].clone() for st in self.flat_state],
+                "layout_version": 2, "layout": self._layout()}
 
     def load_state_dict(self, sd) -> None:
+        """Validates BEFORE copying anything.  A checkpoint with the same per-bucket sizes loads positionally; one written under another
+        bucket layout (round 3: 4 ViT buckets, round 4: 6) is re-mapped by parameter name when it carries its layout, refused otherwise."""
+        ms, vs = list(sd["m"]), list(sd["v"])
+        mine = [int(st["m"].numel()) for st in self.flat_state]
+        if len(ms) != len(vs):
+            raise ValueError("FusedAdamW.load_state_dict: 'm' and 'v' lists differ in length")
+        plan = None
+        if [int(m.numel()) for m in ms] != mine:
+            lay = sd.get("layout")
+            if lay is None:
+                raise ValueError(f"FusedAdamW.load_state_dict: checkpoint buckets {[int(m.numel()) for m in ms]} do not match this model's "
+                                 f"{mine} and the checkpoint carries no layout to re-map by parameter name")
+            src = {name: (bi, int(off), int(n)) for bi, bucket in enumerate(lay) for name, off, n in bucket}
+            plan = []
+            for bi, bucket in enumerate(self._layout()):
+                for name, off, n in bucket:
+                    if name not in src or src[name][2] != n or src[name][1] + n > int(ms[src[name][0]].numel()):
+                        raise ValueError(f"FusedAdamW.load_state_dict: parameter {name!r} ({n} elements) is not in the checkpoint's layout")
+                    plan.append((bi, off, src[name][0], src[name][1], n))
         self.step_count = int(sd["step_count"])
         for g, sg in zip(self.param_groups, sd["param_groups"]):
             g.update(sg)
-        for st, m, v in zip(self.flat_state, sd["m"], sd["v"]):
-            st["m"].copy_(m)
-            st["v"].copy_(v)
+        if plan is None:
+            for st, m, v in zip(self.flat_state, ms, vs):
+                st["m"].copy_(m)
+                st["v"].copy_(v)
+        else:
+            for bi, off, sb, soff, n in plan:
+                self.flat_state[bi]["m"][off:off + n].copy_(ms[sb][soff:soff + n])
+                self.flat_state[bi]["v"][off:off + n].copy_(vs[sb][soff:soff + n])

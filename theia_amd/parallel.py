@@ -129,6 +129,26 @@ class GradBucketReducer:
         self._pending: List = []
         self._side: Optional[torch.cuda.Stream] = None
         self._stage: dict = {}  # bf16 staging buffers, one per bucket (keyed by the flat buffer's address)
+        self._pad: dict = {}    # rs_ag: padded staging buffers for buckets whose length is not a multiple of world
+
+    def connect(self, device) -> None:
+        """backend 'abi': create the RCCL communicator NOW -- a collective rendezvous (``broadcast_object_list`` of the id +
+        ``ncclCommInitRank``) that every rank must reach together, so it belongs in the constructor of the wrapper, not inside the
+        first bucket's hook in the middle of a backward pass (a rank whose backward raised would leave the others hanging there)."""
+        if self.backend == "abi" and self._abi is None and self.world > 1 and torch.device(device).type == "cuda":
+            self._abi = AbiCommunicator(self.pg, torch.device(device))
+
+    def close(self) -> None:
+        """destroy the C-ABI communicator (``theia_comm_destroy``); idempotent"""
+        abi, self._abi = self._abi, None
+        if abi is not None:
+            abi.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ the exchange itself (on whatever stream is current)
     def _exchange(self, buf: torch.Tensor, avg: bool):
@@ -136,13 +156,27 @@ class GradBucketReducer:
         if self.backend == "abi" and buf.is_cuda:
             if self.exchange != "allreduce":
                 raise ValueError("GradBucketReducer: backend 'abi' exchanges with all-reduce only")
-            if self._abi is None:
-                self._abi = AbiCommunicator(self.pg, buf.device)
+            if self._abi is None:  # (a reducer used without TheiaDataParallel: connect() was not called by a constructor)
+                self.connect(buf.device)
             self._abi.allreduce(buf, average=avg)  # stream-ordered on the current (side) stream: nothing to wait for
             return None
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         async_ok = avg or not buf.is_cuda or os.environ.get("THEIA_GLOO_ASYNC") == "1"
-        if self.exchange == "rs_ag" and buf.numel() % self.world == 0:
+        if self.exchange == "rs_ag":
+            n = buf.numel()
+            if n % self.world != 0:
+                # a bucket whose length is not a multiple of world: exchange a zero-padded copy and copy the head back.  (It used to
+                # fall back to an all-reduce silently; the shard boundaries must be the same on every rank, and zeros are neutral.)
+                key = (buf.data_ptr(), n, buf.dtype)
+                pad = self._pad.get(key)
+                if pad is None:
+                    pad = self._pad[key] = torch.zeros((n + self.world - 1) // self.world * self.world, dtype=buf.dtype, device=buf.device)
+                pad[:n].copy_(buf)
+                work = self._exchange(pad, avg)
+                if work is not None:
+                    work.wait()  # stream-level on RCCL; the copy below is ordered behind it
+                buf.copy_(pad[:n])
+                return None
             shards = buf.view(self.world, -1)
             mine = shards[self.rank]
             if dist.get_backend(self.pg) == "nccl":
@@ -278,6 +312,8 @@ class TheiaDataParallel(torch.nn.Module):
         if self.reducer.world > 1:
             module.engine.bucket_ready_hook = self._on_bucket
             first = next(iter(module.parameters()), None)
+            if first is not None and first.is_cuda:
+                self.reducer.connect(first.device)  # collective: every rank constructs its wrapper at the same point
             if first is not None and first.is_cuda and dist.get_backend(process_group) == "nccl":
                 self._reserve = reserved_cus()
 
