@@ -7,12 +7,18 @@
 #include <vector>
 #include <string>
 #include "../theia_amd/csrc/gemm_pp.hip"
+#ifdef WITH_W4  // the one-wave-per-SIMD experiment (tools/experiments/gemm_w4.hip, tile 256004): not kept, not in the library
+#include "experiments/gemm_w4.hip"
+#endif
 #ifdef WITH_DW  // the dual-workgroup experiment (tools/experiments/gemm_dw.hip): not kept, not in the library
 #include "experiments/gemm_dw.hip"
 #endif
 
 // tile request -> kernel: 256256 / 320256 = the 8-wave ping-pong kernel, 128256 / 160256 = the dual-workgroup kernel
 static int launch_any(const theia_gemm_args_t* g, hipStream_t s) {
+#ifdef WITH_W4
+    if (g->tile == 256004) return theia_gemm_nt_w4_launch(g, THEIA_BF16, s);
+#endif
 #ifdef WITH_DW
     if (g->tile == 128256 || g->tile == 160256) return theia_gemm_nt_dw_launch(g, THEIA_BF16, s);
 #endif
@@ -171,6 +177,23 @@ int main(int argc, char** argv) {
         }
         g_pp_grid_cap = 0;
         g_dw_grid_cap = 0;
+#ifdef WITH_W4
+        if (!getenv("PPB_NO_W4")) {
+            for (int cap = 0; cap <= 5; cap += 5) {
+                g_w4_grid_cap = cap;
+                printf("-- w4 (one wave per SIMD), persistent grid cap %d\n", cap);
+                const int t = 256004;
+                fails += check_one(b, 1000, 768, 768, THEIA_ACT_NONE, false, false, t);
+                fails += check_one(b, 1000, 768, 768, THEIA_ACT_NONE, true, false, t);
+                fails += check_one(b, 1187, 1024, 1024, THEIA_ACT_NONE, true, false, t);   // ragged M
+                fails += check_one(b, 333, 256, 512, THEIA_ACT_NONE, true, false, t);      // the shortest K, one column tile
+                fails += check_one(b, 700, 768, 3072, THEIA_ACT_NONE, true, false, t);
+                fails += check_one(b, 700, 3072, 768, THEIA_ACT_GELU, true, false, t);
+                fails += check_one(b, 1100, 1024, 1536, THEIA_ACT_GELU, true, false, t);    // GELU with plain k-steps behind the chunk steps
+            }
+            g_w4_grid_cap = 0;
+        }
+#endif
         printf("%d failures\n", fails);
     }
     if (what == "time" || what == "all") {
@@ -193,6 +216,15 @@ int main(int argc, char** argv) {
 #endif
             const double fl = 2.0 * s.M * s.N * s.K;
             theia_gemm_args_t g = make_args(b, s.M, s.N, s.K, s.act, s.bias, s.resid, 0);
+#ifdef WITH_W4
+            {
+                theia_gemm_args_t g4 = make_args(b, s.M, s.N, s.K, s.act, s.bias, s.resid, 256004);
+                if (theia_gemm_nt_w4_supported(&g4, THEIA_BF16)) {
+                    const double t4 = time_one(b, s.M, s.N, s.K, s.act, s.bias, s.resid, 256004, iters);
+                    printf("%s M=%6d N=%4d K=%4d: W4    %7.1f us %7.1f TF\n", s.name, s.M, s.N, s.K, t4, fl / t4 / 1e6);
+                }
+            }
+#endif
             printf("%s M=%6d N=%4d K=%4d: BM256 %7.1f us %7.1f TF | BM320 %7.1f us %7.1f TF | auto -> %d || dw128 %7.1f us %7.1f TF | dw160 %7.1f us %7.1f TF | auto -> %d\n",
                    s.name, s.M, s.N, s.K, t256, fl / t256 / 1e6, t320, fl / t320 / 1e6, theia_gemm_nt_pp_bm(&g, THEIA_BF16), t128, fl / t128 / 1e6, t160,
                    fl / t160 / 1e6, theia_gemm_nt_dw_bm(&g, THEIA_BF16));
@@ -228,6 +260,26 @@ int main(int argc, char** argv) {
                 printf("\n");
                 int lead = 0; for (int k = 0; k < 512; ++k) lead += (ids[k][1] & 0xfff) == 0;
                 printf("  blocks with LDS base 0: %d of 512\n", lead);
+            }
+        }
+    }
+#endif
+#if defined(W4_TRACE) && defined(WITH_W4)
+    {
+        struct S { const char* name; int M, N, K, act; bool bias, resid; };
+        const S cfg[] = {{"fc1 gelu w4", 25216, 3072, 768, THEIA_ACT_GELU, true, false}, {"qkv none w4", 25216, 2304, 768, THEIA_ACT_NONE, true, false},
+                         {"fc1_d none w4", 25216, 768, 3072, THEIA_ACT_NONE, false, false}, {"proj_d none w4", 25216, 768, 768, THEIA_ACT_NONE, false, false}};
+        for (const S& c : cfg) {
+            theia_gemm_args_t g = make_args(b, c.M, c.N, c.K, c.act, c.bias, c.resid, 256004);
+            for (int rep = 0; rep < 4; ++rep) launch_any(&g, 0);
+            hipDeviceSynchronize();
+            unsigned long long ph[4][16];
+            hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_w4_phase), sizeof(ph));
+            printf("%s: block 0 stamps (entry, prologue issued, first fragments, then per tile: start, unrolled part done, tile done; [15] exit)\n", c.name);
+            for (int wv = 0; wv < 4; wv += 3) {
+                printf("  wave %d:", wv);
+                for (int k = 0; k < 16; ++k) printf(" %7lld", (long long)(ph[wv][k] - ph[0][0]));
+                printf("\n");
             }
         }
     }
