@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define THEIA_ABI_VERSION 9
+#define THEIA_ABI_VERSION 10
 
 enum { THEIA_OK = 0, THEIA_ERR_INVALID = -1, THEIA_ERR_LAUNCH = -2, THEIA_ERR_UNSUPPORTED = -3 };
 enum { THEIA_F32 = 0, THEIA_BF16 = 1,
@@ -47,6 +47,17 @@ int theia_dtype_size(int dtype);
  * Environment: THEIA_COMPUTE_CUS (initial value). */
 int theia_set_compute_cus(int n);
 int theia_get_compute_cus(void);
+/* Tile schedule of the persistent NT GEMM (theia_gemm_nt, tiles 256256 / 320256; ABI v10).  0 = static rounds: workgroup w owns tiles w,
+ * w + grid, ... -- the fastest schedule when the launch has the chip to itself (default).  1 = work-conserving: the schedule's positions
+ * become one queue per XCD and a workgroup draws its next tile from the queue of the XCD it runs on (a scalar atomic on a per-launch
+ * counter; the same L2 locality as the static rounds), so a launch that shares the chip -- RCCL channels at N > 1, another stream's
+ * one-workgroup-per-CU kernels -- degrades in proportion to the CUs it actually gets instead of waiting for its late workgroups' whole
+ * shares.  Measured alone the queues cost 3-8 % of a launch (profiles/r05_dynamic_tile_schedule.txt), hence opt-in.  Host-side state read
+ * when a launch is enqueued; launches with K below 8 half k-tiles and launches recorded into a stream capture always use the static
+ * schedule.  Returns the previous setting.  Environment: THEIA_PP_DYNAMIC (initial value).  Replaces nothing in the reference (cuBLAS /
+ * DDP leave tile scheduling to the hardware): train_rvfm.py:125,258 is where the sharing arises. */
+int theia_set_gemm_schedule(int dynamic);
+int theia_get_gemm_schedule(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Row map: how GEMM row m of the (implicitly gathered) activation operand and of the output is found.

@@ -25,8 +25,19 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/theia_hip.h but not exported"
     assert sorted(N.EXPORTED_SYMBOLS) == declared, "ctypes signature table and header disagree"
-    assert lib.theia_abi_version() == N.ABI_VERSION == 9
+    assert lib.theia_abi_version() == N.ABI_VERSION == 10
     assert lib.theia_dtype_size(N.F32) == 4 and lib.theia_dtype_size(N.BF16) == 2 and lib.theia_dtype_size(7) == -1
+
+
+def test_gemm_schedule_switch_is_host_state():
+    """theia_set_gemm_schedule / theia_get_gemm_schedule (ABI v10): host-side state of the persistent NT GEMM's tile schedule, static by
+    default, returns the previous setting (no launch involved)."""
+    from theia_amd import ops
+    first = ops.get_gemm_schedule()
+    assert first == (os.environ.get("THEIA_PP_DYNAMIC", "0") not in ("0", ""))
+    assert ops.set_gemm_schedule(True) == first and ops.get_gemm_schedule() is True
+    assert ops.set_gemm_schedule(False) is True and ops.get_gemm_schedule() is False
+    ops.set_gemm_schedule(first)
 
 
 def test_struct_layout_matches_header(tmp_path):

@@ -24,11 +24,22 @@ def _resources(fname, tmp):
     text = open(out).read()
     if fname == "gemm_pp.hip":
         _steady_loops_are_scratch_free(text)
+        _reserved_sgpr_is_untouched(text)
     names = re.findall(r"^\s*\.amdhsa_kernel\s+(\S+)", text, re.M)
     scratch = [int(x) for x in re.findall(r"^; ScratchSize:\s+(\d+)", text, re.M)]
     vgprs = [int(x) for x in re.findall(r"^; NumVgprs:\s+(\d+)", text, re.M)]
     assert len(names) == len(scratch) == len(vgprs) and names, fname
     return [(fname, n, s, v) for n, s, v in zip(names, scratch, vgprs)]
+
+
+def _reserved_sgpr_is_untouched(text):
+    """The work-conserving tile schedule keeps the returned value of its asynchronous scalar atomic in s100 from the issue (one asm
+    statement) to the wait a half-tile later (another one).  That only works because the compiler never allocates s100
+    (amdgpu_num_sgpr(96) on the kernel): every mention of s100 / s101 in the assembly must be one of the three hand-written forms."""
+    ok = re.compile(r"^\s*(s_mov_b32 s100, 1|s_atomic_add s100, s\[\d+:\d+\], 0x0 glc|s_mov_b32 s\d+, s100)\s*$")
+    hits = [l for l in text.split("\n") if re.search(r"\bs10[01]\b|\bs\[(9\d|100):10\d\]", l) and not l.strip().startswith((";", "."))]
+    assert hits and all(ok.match(l) for l in hits), [l for l in hits if not ok.match(l)][:5]
+    assert sum("s_atomic_add s100" in l for l in hits) >= 2 * 8  # the first draw + the in-loop draw, in every instantiation
 
 
 def _steady_loops_are_scratch_free(text):

@@ -54,7 +54,7 @@ def rnd(x, dt):
 def test_library_loads_and_abi():
     from theia_amd import _native as N
     lib = N.lib()
-    assert lib.theia_abi_version() == N.ABI_VERSION == 9
+    assert lib.theia_abi_version() == N.ABI_VERSION == 10
     assert lib.theia_dtype_size(N.BF16) == 2
 
 
@@ -1077,3 +1077,65 @@ def test_layernorm_statistics_with_a_residual_run_on_the_2stage_kernel():
     for tile in (256256, 256009):
         with pytest.raises(Nn.TheiaNativeError, match="ln_sums together with resid"):
             ops.gemm_nt(xd, wf, out, b * mpi, C, 9 * C, rmap, 9 * C, C, tile=tile, **kw)
+
+
+@pytest.mark.parametrize("tile", [256256, 320256])
+def test_work_conserving_tile_schedule_is_bit_identical_to_the_static_rounds(tile):
+    """theia_set_gemm_schedule(1) (ABI v10): the persistent NT kernel draws its tiles from per-XCD queues (scalar atomics on a per-launch
+    counter) instead of owning them by workgroup index.  Same tiles, same arithmetic: the outputs must be BIT-IDENTICAL to the static
+    schedule -- on one-round launches, on launches of several rounds, with the CU budget squeezed to 40 (every workgroup walks over many
+    tiles and the queues run dry at different times), with every epilogue flavour that changes what a tile boundary carries (bias row
+    prefetch, residual rows = the draining boundary, GELU + saved pre-activation, GELU'), and when a second stream keeps CUs busy."""
+    from theia_amd import ops, _native as Nn
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    cases = [(25216, 768, 768, "resid"), (6000, 3072, 768, "gelu"), (6000, 768, 3072, "plain"), (3000, 3072, 768, "dgelu"), (5000, 1024, 256, "plain")]
+    prev = ops.set_gemm_schedule(False)
+    cus0 = ops.get_compute_cus()
+    try:
+        for budget in (0, 40):
+            ops.set_compute_cus(budget)
+            for (M, N, K, kind) in cases:
+                x = (torch.randn(M, K, generator=g)).to(dev, torch.bfloat16)
+                w = (torch.randn(N, K, generator=g) * 0.05).to(dev, torch.bfloat16)
+                b = torch.randn(N, generator=g).to(dev)
+                r = torch.randn(M, N, generator=g).to(dev, torch.bfloat16)
+                outs = []
+                for dyn in (False, True, True):
+                    ops.set_gemm_schedule(dyn)
+                    assert ops.get_gemm_schedule() == dyn
+                    pre = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+                    if kind == "resid":
+                        y = ops.linear(x, w, b, resid=r, tile=tile)
+                    elif kind == "gelu":
+                        y = ops.linear(x, w, b, act=Nn.ACT_GELU, aux_out=pre, tile=tile)
+                    elif kind == "dgelu":
+                        y = ops.linear(x, w, None, act=Nn.ACT_MUL_DGELU, aux_in=r, tile=tile)
+                    else:
+                        y = ops.linear(x, w, b, tile=tile)
+                    outs.append((y.clone(), pre.clone()))
+                torch.cuda.synchronize()
+                for (y, pre) in outs[1:]:
+                    assert torch.equal(y, outs[0][0]) and torch.equal(pre, outs[0][1]), (budget, M, N, K, kind)
+        # a launch that does not have the chip to itself: a long GEMM on a second stream holds CUs while the dynamic launches run
+        ops.set_compute_cus(0)
+        M, N, K = 25216, 3072, 768
+        x = torch.randn(M, K, generator=g).to(dev, torch.bfloat16)
+        w = (torch.randn(N, K, generator=g) * 0.05).to(dev, torch.bfloat16)
+        b = torch.randn(N, generator=g).to(dev)
+        ops.set_gemm_schedule(False)
+        ref = ops.linear(x, w, b, tile=tile).clone()
+        big_x = torch.randn(32768, 3072, generator=g).to(dev, torch.bfloat16)
+        big_w = (torch.randn(768, 3072, generator=g) * 0.05).to(dev, torch.bfloat16)
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        ops.set_gemm_schedule(True)
+        for rep in range(3):
+            with torch.cuda.stream(side):
+                ops.linear(big_x, big_w, None, tile=256256)
+            y = ops.linear(x, w, b, tile=tile)
+            torch.cuda.synchronize()
+            assert torch.equal(y, ref), rep
+    finally:
+        ops.set_gemm_schedule(prev)
+        ops.set_compute_cus(cus0 if cus0 != ops.device_cus() else 0)

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtheia_hip.so")
 
 F32, BF16, FP8 = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 COMM_ID_BYTES = 128  # THEIA_COMM_ID_BYTES
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_MUL_DGELU, ACT_MUL_DRELU = 0, 1, 2, 3, 4
 MAX_TAPS = 9
@@ -86,6 +86,8 @@ _SIGNATURES = {
     "theia_gemm_wgrad_plan": (C.c_int, [C.POINTER(WgradArgs), C.c_int]),
     "theia_set_compute_cus": (C.c_int, [C.c_int]),
     "theia_get_compute_cus": (C.c_int, []),
+    "theia_set_gemm_schedule": (C.c_int, [C.c_int]),
+    "theia_get_gemm_schedule": (C.c_int, []),
     "theia_wgrad_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
                                      C.c_int64, C.c_int, C.c_void_p]),
     "theia_wgrad_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int,

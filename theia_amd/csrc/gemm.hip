@@ -613,7 +613,16 @@ extern "C" int theia_wgrad_splits_taps(int M, int N, int kslots, int in_c) {
         // ping-pong kernel: 256x256 output tiles (per tap; the last c tile of a tap may be partial), one workgroup per CU -> fill one
         // round of the CU budget as exactly as possible
         const int tiles = cdiv_i(N, 256) * kslots * cdiv_i(in_c, 256);
-        int s = theia_compute_cus() / (tiles > 0 ? tiles : 1);
+        // THEIA_WGRAD_CUS: workgroups (= CUs) a weight-gradient launch may fill -- fewer splits, each longer, and the rest of the chip stays
+        // free for whatever the main stream runs beside it (A/B switch of the round-5 overlap experiments; default: the whole budget)
+        static int wg_cus = -1;
+        if (wg_cus < 0) {
+            const char* e = getenv("THEIA_WGRAD_CUS");
+            wg_cus = e != nullptr && atoi(e) > 0 ? atoi(e) : 0;
+        }
+        int budget = theia_compute_cus();
+        if (wg_cus > 0 && wg_cus < budget) budget = wg_cus;
+        int s = budget / (tiles > 0 ? tiles : 1);
         const int smax = cdiv_i(M, 32) / 8;
         if (s > smax) s = smax;
         if (s > 64) s = 64;

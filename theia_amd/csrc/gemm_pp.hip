@@ -50,11 +50,16 @@ __device__ unsigned long long g_pp_phase[8][16];
 
 __device__ __forceinline__ int pp_f(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
+// SGPRs the compiler may allocate: s100 / s101 stay out of its hands -- they carry the asynchronous tile draw of the work-conserving
+// schedule from its issue to its wait (see "work-conserving schedule" in the kernel)
+#define PP_NUM_SGPR 96
+
 template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // T: operand type.  BM: tile rows.  TAPS: multi-tap (3x3 gather) row maps; false = single-tap maps only.  SUMS: ln_sums epilogue.
 template <typename T, int BM, bool TAPS, bool SUMS>
-__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t p, const int ntiles, const int panel) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(PP_NUM_SGPR))) void gemm_nt_pp_kernel(const theia_gemm_args_t p, const int ntiles,
+                                                                                                     const int panel, unsigned* const sched) {
     constexpr int BN = 256, WAVES_N = 4;
     constexpr int NSTAGE = 4;
     constexpr int HKT = 64 / (int)sizeof(T);
@@ -102,6 +107,64 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
         const int m = rem / cols, n = pi * panel + (rem - m * cols);
         return m * tiles_n + n;
     };
+    // ---------------------------------------------------------------- work-conserving schedule (sched != nullptr; round 5)
+    // With static ownership a workgroup that starts late -- its CU held by an RCCL channel, or by a weight-gradient workgroup of the side
+    // stream -- still owns a full share of the tiles, so the launch takes as long as that CU stays away plus a whole share.  Dynamic
+    // mode: the schedule positions above become eight QUEUES, one per XCD (position r * grid + q belongs to the XCD whose contiguous
+    // range of round r holds q: the same L2 locality as the static rounds), and a workgroup draws its next item from the queue of the XCD
+    // it runs on with a SCALAR atomic (s_atomic_add ... glc on a per-launch counter; tracked by lgkmcnt, which every R segment waits to
+    // zero anyway; the counter lives in that XCD's L2 and only that XCD's workgroups touch it: tools/experiments/satomic_probe.hip --
+    // ~760 cycles per draw, every queue a permutation).  The draw for the next tile is issued by wave 0 six half-tiles before this tile
+    // ends and read one half-tile later; the result reaches the other waves through an LDS word, in time for the operand stream to cross
+    // into it.  Between issue and wait the returned value sits in s100, an SGPR the compiler cannot allocate (amdgpu_num_sgpr): as an
+    // ordinary asm output it was copied into the loop-carried register right behind the issue, before the atomic had returned, and
+    // keeping issue and wait in one straight-line block (a second copy of the M segment) cost 700 spills.
+    // A launch degrades in proportion to the CUs it actually gets; a workgroup that finds its queue empty leaves.
+    const bool dyn = sched != nullptr;
+    int xcc = 0;
+    if (dyn) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7;
+    }
+    unsigned* const my_counter = sched + xcc * 32;  // 128 bytes apart: one line per XCD
+    // item k of XCD x's queue -> tile (or -1 past the end)
+    auto item_tile = [&](int x, int k) {
+        const int nfull = (grid >> 3) + (x < (grid & 7) ? 1 : 0), nlast = (cnt_last >> 3) + (x < (cnt_last & 7) ? 1 : 0);
+        const int head = (rounds - 1) * nfull;
+        int r, idx;
+        if (k < head) {
+            r = k / nfull;
+            idx = k - r * nfull;
+        } else {
+            r = rounds - 1;
+            idx = k - head;
+            if (idx >= nlast) return -1;
+        }
+        const int t = r * grid + gt_xcd_remap(idx * 8 + x, r + 1 < rounds ? grid : cnt_last);
+        if (panel <= 0) return t;
+        const int tiles_m = ntiles / tiles_n;
+        const int per = panel * tiles_m, full = tiles_n / panel;
+        const int pi = min(t / per, full);
+        const int cols = pi < full ? panel : tiles_n - full * panel;
+        const int rem = t - pi * per;
+        const int m = rem / cols, n = pi * panel + (rem - m * cols);
+        return m * tiles_n + n;
+    };
+    int* const mailbox = reinterpret_cast<int*>(smem + NSTAGE * STAGE + 2048 + 64);
+    auto claim_issue = [&]() {  // s100: 1 going in, the queue position coming back (pre-op value)
+        asm volatile("s_mov_b32 s100, 1\n\ts_atomic_add s100, %0, 0x0 glc" ::"s"(my_counter) : "s100", "memory");
+    };
+    auto claim_publish = [&]() {  // the draw has returned: position -> tile, into the LDS word the other waves read
+        int k;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, s100" : "=s"(k)::"memory");
+        const int t = item_tile(xcc, k);
+        asm volatile("ds_write_b32 %0, %1" ::"v"(gt_lds_addr(mailbox)), "v"(t) : "memory");
+    };
+    auto claim_read = [&]() {
+        int t;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(gt_lds_addr(mailbox)) : "memory");
+        return __builtin_amdgcn_readfirstlane(t);
+    };
     const T* __restrict__ A = reinterpret_cast<const T*>(p.a);
     const T* __restrict__ W = reinterpret_cast<const T*>(p.w);
     const int R = mp.rows_h * mp.rows_w;
@@ -114,6 +177,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
     // (TAPS: for the current tap, recomputed when the stream enters a new tap), all wave-uniform except the pointers.
     uint64_t src_ptr[LPH_FULL];
     int pf_r = 0, pf_h = 0, cur_tap = 0, next_tap_h = hpt, pf_m0 = 0, pf_n0 = 0;
+    int tile_next = -1;  // the tile after the one being computed (-1: none, or -- dynamic mode -- not drawn yet)
     // source pointers of tile (pf_m0, pf_n0) for tap `tap`.  Multi-tap maps: out-of-range taps read the zero page; the row decode is
     // redone at every tap switch (once per in_c / HKT half-tiles) rather than carried in registers across the whole kernel.
     // Single-tap maps (TAPS = false): rows beyond M / N are clamped to the last row (their products land in rows / columns that are
@@ -199,10 +263,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
     };
     auto pf_advance = [&]() {
         if (pf_h == nh) {  // wave-uniform
-            if (pf_r + 1 < my_tiles) {
+            // static mode: the stream keeps its own round counter (with K of one to three half-tiles it crosses more than one tile
+            // boundary per tile); dynamic mode (K >= 8 half-tiles): it enters the next tile at most once per tile, and that tile is known
+            if (dyn ? tile_next >= 0 : pf_r + 1 < my_tiles) {
                 ++pf_r;
                 pf_h = 0;
-                setup_tile(tile_of(pf_r));
+                setup_tile(dyn ? tile_next : tile_of(pf_r));
             } else {
                 pf_h = nh - 1;
 #pragma unroll
@@ -353,7 +419,21 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
     };
 
     // ---------------------------------------------------------------- first tile: init rows, then the operand prologue
-    int tile = tile_of(0);
+    int tile;
+    if (dyn) {  // the first tile is drawn like every other one: a workgroup that starts late must not own anything
+        if (uwave == 0) {
+            claim_issue();
+            claim_publish();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        tile = claim_read();
+        if (tile < 0) return;  // (wave-uniform) every item of this XCD's queue has been taken by workgroups that started earlier
+    } else {
+        tile = tile_of(0);
+        tile_next = my_tiles > 1 ? tile_of(1) : -1;
+    }
     int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     start_tile(std::true_type{}, tile, m0 + wm * WM, n0 + wn * WN);
     __builtin_amdgcn_sched_barrier(0);
@@ -387,7 +467,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
     if constexpr (SUMS) {
         if (threadIdx.x < 2 * GT_SUMS_SLOTS) sums_tab[threadIdx.x] = 0ull;  // (first use: behind every barrier of the first main loop)
     }
-    for (int r = 0; r < my_tiles; ++r) {
+    const int h_claim = nh - 6;  // dynamic mode (host: nh >= 8): wave 0 draws at h_claim, publishes at h_claim + 1, every wave reads at nh - 4
+    for (int r = 0;; ++r) {
         // Fragment addresses: rows 16 apart share the swizzle (pp_f looks at bits 2..3 of the row), so the FM A fragments / 4 B
         // fragments of a wave are 1 KiB apart: one lane-dependent offset each + immediates.  The reads are inline asm (see
         // gt_ds_read128: a C++ load here would make the compiler drain every in-flight LDS-DMA at the top of each iteration).
@@ -407,12 +488,15 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
             asm volatile("" ::: "memory");
         }
         PP_PHASE(3 + 4 * r)
-        const int tile_next = r + 1 < my_tiles ? tile_of(r + 1) : tile;
-        const int m0_next = (tile_next / tiles_n) * BM, n0_next = (tile_next % tiles_n) * BN;
-        const bool fetch_bias = BIAS_IN_ACC && seamless && p.bias != nullptr && uwave == 0 && r + 1 < my_tiles;  // wave-uniform
+        // the tile after this one: static mode knows it now; dynamic mode learns it at h = nh - 4, in front of the pf_advance() that
+        // enters it (the operand stream runs three half-tiles ahead) and of the bias fetch at nh - 3
+        if (dyn) tile_next = -1;
+        else tile_next = r + 1 < my_tiles ? tile_of(r + 1) : -1;
         for (int h = 0; h < nh; ++h, ++g) {
             const uint32_t soff = (uint32_t)(g & (NSTAGE - 1)) * STAGE;
-            if (fetch_bias && h == nh - (NSTAGE - 1)) {  // three iterations before the tile ends: covered by the loop's own waits
+            // three iterations before the tile ends: covered by the loop's own waits (wave-uniform condition)
+            if (BIAS_IN_ACC && seamless && p.bias != nullptr && uwave == 0 && tile_next >= 0 && h == nh - (NSTAGE - 1)) {
+                const int n0_next = (tile_next % tiles_n) * BN;
                 const int n = min(n0_next + (int)(threadIdx.x & 63) * 4, p.N - 4);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + n),
                                                  (__attribute__((address_space(3))) void*)(smem + BIAS_LDS + ((r + 1) & 1) * 1024), 16, 0, 0);
@@ -440,6 +524,15 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            if (dyn) {  // (wave-uniform branches; nothing here in static mode)
+                if (h == h_claim) {
+                    if (uwave == 0) claim_issue();
+                } else if (h == h_claim + 1) {
+                    if (uwave == 0) claim_publish();
+                } else if (h == h_claim + 2) {
+                    tile_next = claim_read();
+                }
+            }
             pf_advance();  // tap / tile switch of the prefetch stream, if the next fetch needs one (fragment registers are dead here)
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -456,10 +549,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
             if constexpr (SUMS) flush_img0 = it0;
         }
         PP_PHASE(5 + 4 * r)
-        if (r + 1 < my_tiles) {
+        if (tile_next >= 0) {
             tile = tile_next;
-            m0 = m0_next;
-            n0 = n0_next;
+            m0 = (tile / tiles_n) * BM;
+            n0 = (tile % tiles_n) * BN;
             if (!seamless) {
                 start_tile(std::false_type{}, tile, m0 + wm * WM, n0 + wn * WN);  // rows requested now, queue drained
             } else if constexpr (BIAS_IN_ACC) {  // accumulators = the bias row in LDS (landed and fenced: see above)
@@ -512,6 +605,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
             }
         }
         PP_PHASE(6 + 4 * r)
+        if (tile_next < 0) break;
     }
     if constexpr (SUMS) {  // the last tile's totals
         __builtin_amdgcn_s_barrier();
@@ -523,6 +617,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const theia_gemm_args_t
 }
 
 // ---------------------------------------------------------------------------------------------------------------- launch
+#ifndef PP_DYNAMIC_DEFAULT
+#define PP_DYNAMIC_DEFAULT 0
+#endif
 int g_pp_grid_cap = 0;  // > 0: cap on the persistent grid (tools/pp_bench.hip: forces several tiles per workgroup on small problems)
 static int pp_num_cus() {
     static int forced = -1;
@@ -533,9 +630,64 @@ static int pp_num_cus() {
     return g_pp_grid_cap > 0 ? g_pp_grid_cap : forced > 0 ? forced : theia_compute_cus();
 }
 
+// ---- per-launch tile counters of the work-conserving schedule -------------------------------------------------------------------------
+// One block of 8 counters (one 128-byte line per XCD) per launch, zero when the launch starts.  Blocks come from a per-stream arena that is
+// cleared with ONE stream-ordered memset when it wraps (every PP_SCHED_BLOCKS launches): nothing in the kernel resets a counter, so a
+// launch needs no "last workgroup out" protocol, and the stream order makes the clear safe (every earlier launch of the stream has finished,
+// every later one starts behind it).  A launch recorded into a stream capture would replay with the counters of its first run: captured
+// launches use the static schedule.  THEIA_PP_DYNAMIC=0/1: off / on.
+#include <mutex>
+#include <unordered_map>
+constexpr int PP_SCHED_BLOCKS = 4096, PP_SCHED_BLOCK_BYTES = 8 * 128;
+struct pp_sched_arena_t { unsigned char* base = nullptr; int next = 0; };
+static int pp_dynamic_mode() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("THEIA_PP_DYNAMIC");
+        v = e == nullptr ? PP_DYNAMIC_DEFAULT : (atoi(e) != 0 ? 1 : 0);
+    }
+    return v;
+}
+int g_pp_dynamic_override = -1;  // -1 = environment, 0 / 1 = set through theia_set_gemm_schedule (or by tools/pp_bench.hip)
+#ifndef PP_NO_ABI
+extern "C" int theia_get_gemm_schedule(void) { return g_pp_dynamic_override >= 0 ? g_pp_dynamic_override : pp_dynamic_mode(); }
+extern "C" int theia_set_gemm_schedule(int dynamic) {
+    const int prev = theia_get_gemm_schedule();
+    g_pp_dynamic_override = dynamic != 0 ? 1 : 0;
+    return prev;
+}
+#endif
+static unsigned* pp_sched_block(hipStream_t stream) {
+    static std::mutex mu;
+    static std::unordered_map<hipStream_t, pp_sched_arena_t> arenas;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    pp_sched_arena_t& ar = arenas[stream];
+    if (ar.base == nullptr) {
+        if (hipMalloc(reinterpret_cast<void**>(&ar.base), (size_t)PP_SCHED_BLOCKS * PP_SCHED_BLOCK_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            ar.base = nullptr;
+            return nullptr;
+        }
+        ar.next = PP_SCHED_BLOCKS;  // (cleared on first use, in stream order)
+    }
+    if (ar.next >= PP_SCHED_BLOCKS) {
+        if (hipMemsetAsync(ar.base, 0, (size_t)PP_SCHED_BLOCKS * PP_SCHED_BLOCK_BYTES, stream) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        ar.next = 0;
+    }
+    return reinterpret_cast<unsigned*>(ar.base + (size_t)(ar.next++) * PP_SCHED_BLOCK_BYTES);
+}
+
 template <typename T, int BM, bool TAPS, bool SUMS>
 static int pp_launch_one(const theia_gemm_args_t* a, hipStream_t stream) {
-    constexpr int lds = 4 * (BM + 256) * 64 + 2048 + 64;  // operand ring + two bias rows (this tile's, the next tile's) + statistics table
+    constexpr int lds = 4 * (BM + 256) * 64 + 2048 + 64 + 64;  // operand ring + two bias rows (this tile's, the next tile's) + statistics table + the schedule's word
     auto kern = gemm_nt_pp_kernel<T, BM, TAPS, SUMS>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -560,7 +712,11 @@ static int pp_launch_one(const theia_gemm_args_t* a, hipStream_t stream) {
         if (panel < 1) panel = 1;
         if (panel >= tn) panel = 0;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, *a, tiles, panel);
+    // work-conserving schedule: any launch whose K gives the draw six half-tiles of lead
+    const int nh = a->K / (64 / (int)sizeof(T));
+    const bool want_dyn = (g_pp_dynamic_override >= 0 ? g_pp_dynamic_override : pp_dynamic_mode()) != 0 && nh >= 8;
+    unsigned* sched = want_dyn ? pp_sched_block(stream) : nullptr;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, *a, tiles, panel, sched);
     THEIA_CHECK_LAUNCH("theia_gemm_nt(pp)");
     return THEIA_OK;
 }

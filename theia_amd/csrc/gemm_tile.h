@@ -93,33 +93,25 @@ __device__ __forceinline__ int gt_divmod24(int m, int d, float rcp, int& rem) {
 }
 
 // GELU pieces of the bf16 path.  The f32 (parity) path keeps libm erff.
-// Phi(x) = 0.5 * (1 + erf(x / sqrt 2)) as an odd polynomial: Phi(x) = 0.5 + xc * P((xc / 4.5)^2), xc = clamp(x, +-4.5), P of degree 9
-// (weighted least-squares fit iterated towards minimax; evaluated in f32 Horner form: |error| <= 1.25e-5 over the whole real line,
-// the clamp's tail 1 - Phi(4.5) = 3.4e-6 included; bf16 resolves 3.9e-3).  13 plain VALU operations, no transcendental: the
-// Abramowitz-Stegun 7.1.26 form used before (rcp + exp + 14 plain, |error| 1.5e-7) made the GELU epilogue of a 256x256 tile ~15k
-// cycles and the GELU-gradient epilogue ~26k -- VALU-bound, a third / half of a K = 768 tile (tools/pp_bench.hip -DPP_TRACE).
-__device__ __forceinline__ float gt_phi_poly(float x) {
-    const float xc = __builtin_amdgcn_fmed3f(x, -4.5f, 4.5f);
-    const float xs = xc * (1.0f / 4.5f);
-    const float s = xs * xs;
-    float p = -1.050371170e+00f;
-    p = fmaf(p, s, 6.019040585e+00f);
-    p = fmaf(p, s, -1.537067318e+01f);
-    p = fmaf(p, s, 2.330106735e+01f);
-    p = fmaf(p, s, -2.366455650e+01f);
-    p = fmaf(p, s, 1.729463768e+01f);
-    p = fmaf(p, s, -9.533602715e+00f);
-    p = fmaf(p, s, 4.061982155e+00f);
-    p = fmaf(p, s, -1.345344782e+00f);
-    p = fmaf(p, s, 3.989298940e-01f);
-    return fmaf(xc, p, 0.5f);
-}
-// Saturating form: the polynomial is within 1.25e-5 of Phi everywhere, so at the clamp (|x| >= 4.5, Phi = 3.4e-6 / 1 - 3.4e-6) it is
-// some constant in [-9e-6, 1.6e-5] (resp. 1 minus that) -- gelu(-50) would be -50 times that constant instead of 0.  Stretching by
-// (1 + 2 delta) around 1/2 with delta = 1.7e-5 and clamping to [0, 1] pins both tails to exactly 0 / 1 (gelu(x) = 0 for x <= -4.5, = x
-// for x >= 4.5) for two VALU operations; |error| <= 1.25e-5 + 1.7e-5 in between, still 1/100 of a bf16 ulp of Phi.
+// Phi(x) = 0.5 * (1 + erf(x / sqrt 2)) as a logistic function of an odd quintic (round 5; minimax fit on [-4.5, 4.5] with the
+// saturation below included):   Phi(x) ~ 1 / (1 + exp(-(a x + b x^3 + c x^5))),  xc = clamp(x, +-4.5)
+//     |x| * |error| <= 6.5e-5 over the whole real line, i.e. gelu(x) = x * Phi(x) is within 6.5e-5 ABSOLUTE of the erf form (bf16
+//     resolves 3.9e-3 relative; the degree-9 polynomial in x^2 used in rounds 2-4 was within 1.25e-5 * |x| <= 5.6e-5).
+// 10 VALU operations, two of them transcendental (v_exp_f32, v_rcp_f32: quarter rate) instead of 17: the GELU / GELU' epilogues of fc1
+// forward / fc2 data-gradient are VALU-bound (~9k cycles of a 256 x 256 tile, profiles/r04_epilogue_lane_order.txt; the same ~10 us per
+// tile in the one-wave-per-SIMD experiment of round 5).  History: Abramowitz-Stegun 7.1.26 (rcp + exp + 14 plain, round 1: ~15k cycles
+// per tile), the clamped degree-9 polynomial (17 plain, rounds 2-4).
+// Saturating form: stretching by (1 + 2 delta) around 1/2 with delta = 1.7e-5 and clamping to [0, 1] pins both tails to exactly 0 / 1
+// (gelu(x) = 0 for x <= -4.5, = x for x >= 4.5: Phi(-4.5) = 3.4e-6 plus the fit error stay below delta).
 __device__ __forceinline__ float gt_phi_sat(float x) {
-    return __builtin_amdgcn_fmed3f(fmaf(gt_phi_poly(x), 1.000034f, -1.7e-5f), 0.f, 1.f);
+    const float xc = __builtin_amdgcn_fmed3f(x, -4.5f, 4.5f);
+    const float s = xc * xc;
+    // -(a + b s + c s^2) * log2(e): a = 1.594730384, b = 0.07449136885, c = -0.0008378073912
+    float t = fmaf(1.2087006e-03f, s, -1.0746833e-01f);
+    t = fmaf(t, s, -2.3007097e+00f);
+    const float e = __builtin_amdgcn_exp2f(t * xc);
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    return __builtin_amdgcn_fmed3f(fmaf(r, 1.000034f, -1.7e-5f), 0.f, 1.f);
 }
 template <typename T> __device__ __forceinline__ float gt_gelu(float x) {
     if constexpr (sizeof(T) == 2) return x * gt_phi_sat(x);

@@ -282,6 +282,16 @@ def get_compute_cus() -> int:
     return N.lib().theia_get_compute_cus()
 
 
+def set_gemm_schedule(dynamic: bool) -> bool:
+    """Tile schedule of the persistent NT GEMM: False = static rounds (default, fastest alone), True = work-conserving per-XCD queues
+    (for launches that share the chip: RCCL channels at N > 1).  Returns the previous setting.  See theia_hip.h."""
+    return bool(N.lib().theia_set_gemm_schedule(1 if dynamic else 0))
+
+
+def get_gemm_schedule() -> bool:
+    return bool(N.lib().theia_get_gemm_schedule())
+
+
 def wgrad_reduce(slabs: torch.Tensor, splits: int, Nn: int, kslots: int, C: int, out: torch.Tensor, sn: int, ss: int, sc: int,
                  accumulate: bool) -> None:
     N.check(N.lib().theia_wgrad_reduce(slabs.data_ptr(), splits, Nn, kslots, C, out.data_ptr(), sn, ss, sc, int(accumulate),

@@ -139,6 +139,8 @@ static double time_one(const Bufs& b, int M, int N, int K, int act, bool bias, b
 int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
     const std::string what = argc > 1 ? argv[1] : "all";
+    if (getenv("PPB_DYNAMIC")) g_pp_dynamic_override = atoi(getenv("PPB_DYNAMIC"));  // 1: work-conserving tile schedule, 0: static rounds
+    printf("tile schedule: %s\n", g_pp_dynamic_override == 1 ? "dynamic (per-XCD queues)" : g_pp_dynamic_override == 0 ? "static" : "library default");
     const int iters = argc > 2 ? atoi(argv[2]) : 20;
     Bufs b;
     b.cap_a = (size_t)131072 * 3072; b.cap_w = (size_t)3072 * 3072; b.cap_o = (size_t)131072 * 768 > (size_t)25216 * 3072 ? (size_t)131072 * 768 : (size_t)25216 * 3072;
