@@ -254,10 +254,23 @@ def selfcheck_dispatch(fwd_bwd, engine):
         torch.cuda.synchronize()
     finally:
         ops.GEMM_TILE_HINT = prev
-    cur = [b.flat for b in engine.buckets if b.flat is not None]
+    live = [b for b in engine.buckets if b.flat is not None]
+    cur = [b.flat for b in live]
     worst = min(_cos(a, b) for a, b in zip(snap, cur))
+    # per TENSOR as well (review item 9: the gate of the model-level tests, at the batch that is benched): every parameter of >= 4096
+    # elements, its gradient under the library's dispatch against the same gradient on the 2-stage kernels
+    worst_t, worst_name = 1.0, ""
+    for b, sa in zip(live, snap):
+        for name, off, prm in zip(b.names, b.offsets, b.params):
+            n = prm.numel()
+            if n < 4096:
+                continue
+            c = _cos(sa[off:off + n], b.flat[off:off + n])
+            if c < worst_t:
+                worst_t, worst_name = c, name
     rel = abs(la - lb) / abs(lb)
-    return {"ok": bool(rel < 2e-3 and worst > 0.99), "loss_rel_diff": float(f"{rel:.3e}"), "worst_bucket_cosine": round(worst, 6)}
+    return {"ok": bool(rel < 2e-3 and worst > 0.99), "loss_rel_diff": float(f"{rel:.3e}"), "worst_bucket_cosine": round(worst, 6),
+            "worst_tensor_cosine": round(worst_t, 6), "worst_tensor": worst_name}
 
 
 def selfcheck_gemm_ulp(batch, dev):
@@ -326,7 +339,27 @@ def load_traffic(pfx, workload=TRAFFIC_WORKLOAD):
 
 
 # ------------------------------------------------------------------------------------------------ train-step bench
+_DIAG = {}  # what an N > 1 run knows about itself so far: printed with the error if a rank fails (review item 7)
+
+
 def main(argv=None):
+    """`_main` with a net under it for N > 1: a rank that fails prints ONE JSON line (rank 0: stdout, others: stderr) with the error, how
+    many ranks RCCL connected, the exchange settings, the bucket order and the start-up measurements taken so far -- the driver's scaling
+    runs are the only place the RCCL path ever executes, and a bare traceback from one of eight ranks says none of that."""
+    try:
+        return _main(argv)
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001
+        world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        if world > 1:
+            line = {"metric": METRIC, "value": None, "unit": "images/sec", "n_gpus": world, "failed_rank": rank,
+                    "error": f"{type(e).__name__}: {e}"[:2000], **_DIAG}
+            print(json.dumps(line), file=sys.stdout if rank == 0 else sys.stderr, flush=True)
+        raise
+
+
+def _main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -365,6 +398,7 @@ def main(argv=None):
         dist.all_reduce(one)  # the first collective: counts the ranks RCCL actually connected
         rccl_ranks = int(one.item())
         log(f"process group up: backend {dist.get_backend()}, {rccl_ranks} ranks answered the first all-reduce")
+        _DIAG["rccl_ranks"] = rccl_ranks
     if args.mode == "forward_feature":
         return forward_feature_main(args, rank, world, dev)
 
@@ -390,6 +424,10 @@ def main(argv=None):
                           precision=args.precision).to(dev)
     log(f"model built ({sum(p.numel() for p in model.parameters()) / 1e6:.1f} M params)")
     ddp = TheiaDataParallel(model)
+    if world > 1:
+        _DIAG["dp"] = {"backend": ddp.reducer.backend, "exchange": ddp.reducer.exchange, "comm_dtype": ddp.reducer.comm_dtype,
+                       "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
+                       "buckets_mb": [[bk.name, round(bk.numel * 4 / 1e6, 1)] for bk in model.engine.buckets]}
     opt = FusedAdamW(ddp, lr=2e-3 * (args.batch * world) / (64 * 8), betas=(0.9, 0.999), weight_decay=0.01)
 
     b = args.batch
@@ -479,7 +517,10 @@ def main(argv=None):
     if world > 1 and not args.no_dp_autotune:
         # untimed: how many CUs to leave to RCCL during the gradient exchange, measured on this job's own step (parallel.py)
         dp_tune = ddp.autotune_reserved_cus(step)
-        log(f"CU reservation for the gradient exchange: ms/step per candidate {dp_tune} -> {ddp._reserve} CUs")
+        _DIAG["dp"].update({"reservation_autotune_ms_per_step": dp_tune or None, "cus_left_to_rccl_during_backward": ddp._reserve,
+                            "work_conserving_tile_schedule": {"on": bool(ddp.dynamic_schedule), "autotune_ms_per_step": ddp.autotune_dynamic_ms}})
+        log(f"CU reservation for the gradient exchange: ms/step per candidate {dp_tune} -> {ddp._reserve} CUs; work-conserving tile "
+            f"schedule: {ddp.autotune_dynamic_ms} ms/step -> {'on' if ddp.dynamic_schedule else 'off'}")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -624,6 +665,7 @@ def main(argv=None):
                                            "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
                                            "cus_left_to_rccl_during_backward": ddp._reserve,
                                            "reservation_autotune_ms_per_step": dp_tune or None,
+                                           "work_conserving_tile_schedule": {"on": bool(ddp.dynamic_schedule), "autotune_ms_per_step": ddp.autotune_dynamic_ms},
                                            # exchange order = backward-completion order; MB of fp32 per bucket
                                            "buckets_mb": [[bk.name, round(bk.numel * 4 / 1e6, 1)] for bk in model.engine.buckets]},
             "selfcheck": checks if checks else "skipped (--no-selfcheck): unchecked run",

@@ -308,6 +308,8 @@ class TheiaDataParallel(torch.nn.Module):
             broadcast_parameters(module.parameters(), 0, process_group)
         self._callback_queued = False
         self._reserve = 0
+        self.dynamic_schedule = False            # set by autotune_reserved_cus when the work-conserving tile schedule wins on this job
+        self.autotune_dynamic_ms: Optional[float] = None
         self._saved_cus: Optional[int] = None  # the budget in force before this wrapper shrank it (None: not shrunk)
         if self.reducer.world > 1:
             module.engine.bucket_ready_hook = self._on_bucket
@@ -332,7 +334,7 @@ class TheiaDataParallel(torch.nn.Module):
             self._saved_cus = None
 
     def autotune_reserved_cus(self, step_fn: Callable[[], object], candidates=(0, 16, 32, 64), steps: int = 3,
-                              min_gain: float = 0.01) -> dict:
+                              min_gain: float = 0.01, try_dynamic: bool = True) -> dict:
         """Measure, at start-up, how many CUs the GEMM planners should leave to RCCL while gradient buckets are in flight, and keep the
         best: ``step_fn()`` (one whole training step) is timed ``steps`` times per candidate (max over ranks), ``pick_reservation``
         decides.  The persistent NT kernel and the weight-gradient kernel hold a whole CU per workgroup, so a collective that takes k CUs
@@ -361,6 +363,33 @@ class TheiaDataParallel(torch.nn.Module):
             dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.reducer.pg)
             results[int(r)] = float(tt.item())
         self._reserve = pick_reservation(results, min_gain)
+        # ... and the other way of living with collectives that hold CUs: nothing reserved, the persistent NT GEMM on its work-conserving
+        # tile schedule (theia_set_gemm_schedule; alone on the chip it costs 3-8 % of a launch, so it has to earn its place on this job's
+        # own step like a reservation does).  Kept only if it beats the best static arrangement by more than the margin.
+        from . import ops
+        self.autotune_dynamic_ms = None
+        if try_dynamic and hasattr(ops, "set_gemm_schedule"):
+            keep = self._reserve
+            self._reserve = 0
+            prev = ops.set_gemm_schedule(True)
+            try:
+                step_fn()
+                torch.cuda.synchronize(dev)
+                dist.barrier(group=self.reducer.pg)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    step_fn()
+                torch.cuda.synchronize(dev)
+                tt = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.reducer.pg)
+                self.autotune_dynamic_ms = float(tt.item())
+            finally:
+                ops.set_gemm_schedule(prev)
+            if self.autotune_dynamic_ms < results[keep] * (1.0 - min_gain):
+                self.dynamic_schedule = True
+                ops.set_gemm_schedule(True)  # (every rank reaches the same decision: the timings are reduced with MAX)
+            else:
+                self._reserve = keep
         return results
 
     def _on_bucket(self, bucket, side_event=None) -> None:
