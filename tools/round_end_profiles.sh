@@ -1,5 +1,5 @@
-# everything profiles/r0N_* of the default bench is made of, in one call on one box (see profiles/README.md).  usage: tools/round_end_profiles.sh [r04]
-TAG=${1:-r04}
+# everything profiles/r0N_* of the default bench is made of, in one call on one box (see profiles/README.md).  usage: tools/round_end_profiles.sh [r05]
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 bash $R/tools/pmc_bench_traffic.sh $O/pmc > $O/pmc.log 2>&1
 cp $O/pmc/traffic.json $R/profiles/${TAG}_bench_pmc_traffic.json; cp $O/pmc/summary.txt $R/profiles/${TAG}_bench_pmc_traffic.txt
