@@ -120,6 +120,7 @@ class GradBucketReducer:
         if self.backend not in ("torch", "abi"):
             raise ValueError(f"GradBucketReducer: backend={self.backend!r}")
         self._abi: Optional[AbiCommunicator] = None
+        self._owns_abi = False
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.exchange = exchange or os.environ.get("THEIA_DP_EXCHANGE", "allreduce")
@@ -137,11 +138,14 @@ class GradBucketReducer:
         first bucket's hook in the middle of a backward pass (a rank whose backward raised would leave the others hanging there)."""
         if self.backend == "abi" and self._abi is None and self.world > 1 and torch.device(device).type == "cuda":
             self._abi = AbiCommunicator(self.pg, torch.device(device))
+            self._owns_abi = True
 
     def close(self) -> None:
-        """destroy the C-ABI communicator (``theia_comm_destroy``); idempotent"""
+        """destroy the C-ABI communicator this reducer created (``theia_comm_destroy``); idempotent.  A communicator handed in from
+        outside (``reducer._abi = comm``) belongs to its creator and is only dropped."""
         abi, self._abi = self._abi, None
-        if abi is not None:
+        owned, self._owns_abi = getattr(self, "_owns_abi", False), False
+        if abi is not None and owned:
             abi.close()
 
     def __del__(self):
