@@ -313,29 +313,31 @@ NT_KERNEL_SOURCES = ["theia_amd/csrc/gemm_pp.hip", "theia_amd/csrc/gemm_epi_dire
 TRAFFIC_WORKLOAD = ("facebook/deit-base-patch16-224", 128, "bf16")  # what tools/pmc_bench_traffic.sh profiles: the default run
 
 
-def load_traffic(pfx, workload=TRAFFIC_WORKLOAD):
+def load_traffic(pfx, workload=TRAFFIC_WORKLOAD, teachers="cddsv"):
     """HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read inside a timed run, so the number
-    comes from the committed summary of tools/pmc_bench_traffic.sh -- and only if that summary was taken from the kernel
-    sources this run was built from (it records their hash) and on this run's workload (the default one: the mean over a
-    step's launches depends on its shapes); otherwise null."""
-    if tuple(workload) != TRAFFIC_WORKLOAD:
-        return None, None
-    best = None
+    comes from a committed summary of tools/pmc_bench_traffic.sh -- and only if that summary was taken from the kernel
+    sources this run was built from (it records their hash) and on this run's workload (it records that too; summaries of
+    rounds 1-4 carry no workload: they are the default one); otherwise null.  The highest round's matching summary wins."""
+    want_wl = [workload[0], int(workload[1]), workload[2], teachers]
+    default_wl = [TRAFFIC_WORKLOAD[0], TRAFFIC_WORKLOAD[1], TRAFFIC_WORKLOAD[2], "cddsv"]
     pdir = os.path.join(ROOT, "profiles")
-    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        if name.endswith("_bench_pmc_traffic.json"):
-            best = os.path.join(pdir, name)  # highest round wins
-    if best is None:
-        return None, None
-    try:
-        tj = json.load(open(best))
-        if tj.get("_kernel_src_sha") != src_sha(NT_KERNEL_SOURCES):
-            return None, os.path.basename(best) + " (stale: kernel sources changed since it was taken)"
-        want = {"bf16": "gemm_nt_pp_kernel<bf16, *> (all instantiations)", "f32": "gemm_nt_pp_kernel<float, *> (all instantiations)",
-                "fp8": "gemm_nt_pp_kernel<fp8_t, *> (all instantiations)"}[pfx]
-        return (tj[want]["hbm_bytes_per_launch"] if want in tj else None), os.path.basename(best)
-    except Exception:  # a malformed summary must not break the benchmark
-        return None, None
+    stale = None
+    for name in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
+        if "_bench_pmc_traffic" not in name or not name.endswith(".json"):
+            continue
+        try:
+            tj = json.load(open(os.path.join(pdir, name)))
+            if tj.get("_workload", default_wl) != want_wl:
+                continue
+            if tj.get("_kernel_src_sha") != src_sha(NT_KERNEL_SOURCES):
+                stale = stale or name + " (stale: kernel sources changed since it was taken)"
+                continue
+            want = {"bf16": "gemm_nt_pp_kernel<bf16, *> (all instantiations)", "f32": "gemm_nt_pp_kernel<float, *> (all instantiations)",
+                    "fp8": "gemm_nt_pp_kernel<fp8_t, *> (all instantiations)"}[pfx]
+            return (tj[want]["hbm_bytes_per_launch"] if want in tj else None), name
+        except Exception:  # a malformed summary must not break the benchmark
+            continue
+    return None, stale
 
 
 # ------------------------------------------------------------------------------------------------ train-step bench
@@ -608,7 +610,7 @@ def _main(argv=None):
             iso_tf = achieved
         kname = (f"gemm_nt_pp_kernel<{pfx}> (theia_gemm_nt: persistent ping-pong kernel, 256x256 / 320x256 tiles)" if dom_var == "pingpong"
                  else f"gemm_nt_kernel<{pfx},{dom_var.replace('x', ',')}> (theia_gemm_nt)")
-        traffic, traffic_src = load_traffic(pfx, (args.backbone, b, args.precision)) if dom_var == "pingpong" else (None, None)
+        traffic, traffic_src = load_traffic(pfx, (args.backbone, b, args.precision), args.teachers) if dom_var == "pingpong" else (None, None)
         roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK / 1e12,
                     "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
                     # minimum HBM bytes per launch (mean over the same launches): operands read once + outputs written once + the

@@ -1,6 +1,7 @@
 #!/bin/bash
 # HBM-side traffic of every kernel of the default bench step: two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot
-# share a pass; kernel-trace only), then tools/pmc_summary.py.  usage: tools/pmc_bench_traffic.sh <outdir>
+# share a pass; kernel-trace only), then tools/pmc_summary.py.  usage: [PMC_BENCH_ARGS="--backbone ... --batch ..."] tools/pmc_bench_traffic.sh <outdir>
+# (PMC_BENCH_ARGS: another workload than the default one; the summary records it as "_workload" and bench.py matches on it)
 set -u
 OUT=$1
 cd /tmp && export TMPDIR=/tmp
@@ -8,7 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o pmc -- \
-      python $REPO/bench.py --steps 2 --warmup 1 --no-roofline --no-cpu-baseline --no-selfcheck > $OUT/$c.log 2>&1
+      python $REPO/bench.py ${PMC_BENCH_ARGS:-} --steps 2 --warmup 1 --no-roofline --no-cpu-baseline --no-selfcheck > $OUT/$c.log 2>&1
 done
 python $REPO/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
 python - "$OUT/summary.txt" <<'PY'
@@ -44,6 +45,12 @@ h = hashlib.sha256()
 for f in ("theia_amd/csrc/gemm_pp.hip", "theia_amd/csrc/gemm_epi_direct.h", "theia_amd/csrc/gemm_tile.h"):  # = bench.py NT_KERNEL_SOURCES
     h.update(open(os.path.join(root, f), "rb").read())
 out["_kernel_src_sha"] = h.hexdigest()[:16]
+# the workload the counters belong to (backbone, per-GPU batch, precision, teacher set): parsed from PMC_BENCH_ARGS with bench.py's defaults
+import shlex
+a = shlex.split(os.environ.get("PMC_BENCH_ARGS", ""))
+def opt(flag, default):
+    return a[a.index(flag) + 1] if flag in a else default
+out["_workload"] = [opt("--backbone", "facebook/deit-base-patch16-224"), int(opt("--batch", "128")), opt("--precision", "bf16"), opt("--teachers", "cddsv")]
 json.dump(out, open(sys.argv[1].replace("summary.txt", "traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if "gemm" in k}, indent=1))
 PY
