@@ -92,6 +92,9 @@ def parse(argv=None):
     ap.add_argument("--no-selfcheck", action="store_true", help="tuning runs only: the printed line is marked unchecked")
     ap.add_argument("--no-dp-autotune", action="store_true", help="N > 1: skip the start-up measurement of the CU reservation for RCCL")
     ap.add_argument("--no-optimizer", action="store_true", help="exclude the AdamW update from the step")
+    ap.add_argument("--teacher-dtype", default="auto", choices=["auto", "bf16", "fp32"],
+                    help="dtype of the resident teacher features.  auto = SURVEY.md 8(d): bf16 for the throughput modes (bf16 / fp8 -- the "
+                         "reference's features ARE bf16 values, data_utils.py:374-379), fp32 for --precision fp32")
     return ap.parse_args(argv)
 
 
@@ -437,9 +440,10 @@ def _main(argv=None):
     images = torch.randint(0, 256, (b, 224, 224, 3), dtype=torch.uint8, generator=g).to(dev)
     g2 = torch.Generator(device="cpu").manual_seed(1000 + rank)
     targets = {}
+    teacher_dtype = torch.float32 if args.teacher_dtype == "fp32" or (args.teacher_dtype == "auto" and args.precision == "fp32") else torch.bfloat16
     for t in TEACHERS:
         C, H, W = get_model_feature_size(t, keep_spatial=True)
-        targets[t] = torch.randn(b, H * W, C, generator=g2).to(dev)
+        targets[t] = torch.randn(b, H * W, C, generator=g2).to(dev).to(teacher_dtype)
 
     def fwd_bwd():
         opt.zero_grad(set_to_none=True)
@@ -661,6 +665,7 @@ def _main(argv=None):
             "dtype": {"bf16": "bf16", "fp8": "fp8 e4m3 operands (fwd + dgrad GEMMs), f32 accumulate, bf16 out; bf16 wgrad"}.get(args.precision, "f32"),
             "data": "synthetic",
             "config": {"workload": f"{args.backbone.split('/')[-1]} student + {len(TEACHERS)} teacher{'s' if len(TEACHERS) > 1 else ''} ({args.teachers}), per-GPU batch {b}, "
+                                   f"teacher features resident as {'bf16' if teacher_dtype == torch.bfloat16 else 'fp32'}, "
                                    f"loss 0.9*cos+0.1*smoothL1, step = fwd+loss+bwd+grad all-reduce" +
                                    ("" if args.no_optimizer else "+fused AdamW") + (", one hipGraph replay per step" if args.graph else ""),
                        "global_batch": b * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},

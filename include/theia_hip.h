@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define THEIA_ABI_VERSION 10
+#define THEIA_ABI_VERSION 11
 
 enum { THEIA_OK = 0, THEIA_ERR_INVALID = -1, THEIA_ERR_LAUNCH = -2, THEIA_ERR_UNSUPPORTED = -3 };
 enum { THEIA_F32 = 0, THEIA_BF16 = 1,
@@ -341,6 +341,13 @@ int theia_distill_loss_fwd(const void* pred, const float* target, float* losses,
 int theia_distill_loss_bwd(const void* pred, const float* target, const float* coef, const float* w, void* dpred,
                            int b, int64_t E, int dtype, void* stream);
 size_t theia_distill_loss_workspace_bytes(int b, int64_t E);
+/* v11: the same with the teacher features in `target_dtype`: THEIA_F32, or THEIA_BF16 beside bf16 predictions -- the reference's loader
+ * produces them by bf16 arithmetic and widens them (dataset/data_utils.py:374-379), so a bf16 target holds the same values and the
+ * results are bit-identical; each of the two passes reads 2 bytes less per element. */
+int theia_distill_loss_fwd_t(const void* pred, const void* target, int target_dtype, float* losses, float* coef, float* workspace,
+                             int b, int64_t E, int dtype, void* stream);
+int theia_distill_loss_bwd_t(const void* pred, const void* target, int target_dtype, const float* coef, const float* w, void* dpred,
+                             int b, int64_t E, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K15: token selection / pooling (models/utils.py:31-43).  x: [b, n, D]; mode 0: x[:, 1:n-disc] -> [b, n-1-disc, D];

@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/theia_hip.h but not exported"
     assert sorted(N.EXPORTED_SYMBOLS) == declared, "ctypes signature table and header disagree"
-    assert lib.theia_abi_version() == N.ABI_VERSION == 10
+    assert lib.theia_abi_version() == N.ABI_VERSION == 11
     assert lib.theia_dtype_size(N.F32) == 4 and lib.theia_dtype_size(N.BF16) == 2 and lib.theia_dtype_size(7) == -1
 
 

@@ -726,6 +726,25 @@ def test_distill_loss_against_oracle_and_golden(dt, golden_dir):
         assert abs(float(got[2]) - float(g10["smooth_l1"])) < 1e-5 * float(g10["smooth_l1"])
 
 
+def test_distill_loss_with_bf16_teacher_features_is_bit_identical():
+    """The reference's loader normalises the stored bf16 features in bf16 and widens them (data_utils.py:374-379): a bf16 target tensor
+    holds the same values as the f32 one the reference feeds, so the bf16-target kernels (ABI v11) must give the same bits -- and
+    anything but f32, or bf16 beside bf16 predictions, is refused."""
+    from theia_amd import ops
+    dev = _dev()
+    b, E = 5, 4096 * 32 + 64
+    p = h((b, E), 81, 2.0).to(dev, torch.bfloat16)
+    q16 = h((b, E), 82, 2.0).to(dev, torch.bfloat16)
+    q32 = q16.float()
+    l32, c32 = ops.distill_loss_fwd(p, q32)
+    l16, c16 = ops.distill_loss_fwd(p, q16)
+    assert torch.equal(l32, l16) and torch.equal(c32, c16)
+    w = torch.tensor([0.2, 0.9, 0.1], device=dev)
+    assert torch.equal(ops.distill_loss_bwd(p, q32, c32, w), ops.distill_loss_bwd(p, q16, c16, w))
+    with pytest.raises(RuntimeError):
+        ops.distill_loss_fwd(p.float(), q16)  # bf16 targets beside f32 predictions
+
+
 @pytest.mark.parametrize("channels_last", [True, False])
 def test_patchify_bit_exact_indexing(channels_last):
     from theia_amd import ops

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtheia_hip.so")
 
 F32, BF16, FP8 = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 COMM_ID_BYTES = 128  # THEIA_COMM_ID_BYTES
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_MUL_DGELU, ACT_MUL_DRELU = 0, 1, 2, 3, 4
 MAX_TAPS = 9
@@ -123,6 +123,8 @@ _SIGNATURES = {
     "theia_distill_loss_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "theia_distill_loss_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "theia_distill_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
+    "theia_distill_loss_fwd_t": (C.c_int, [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int64, C.c_int, C.c_void_p]),
+    "theia_distill_loss_bwd_t": (C.c_int, [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "theia_token_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "theia_resize_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -59,7 +59,8 @@ template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_
 // T: operand type.  BM: tile rows.  TAPS: multi-tap (3x3 gather) row maps; false = single-tap maps only.  SUMS: ln_sums epilogue.
 template <typename T, int BM, bool TAPS, bool SUMS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(PP_NUM_SGPR))) void gemm_nt_pp_kernel(const theia_gemm_args_t p, const int ntiles,
-                                                                                                     const int panel, unsigned* const sched) {
+                                                                                                     const int panel, unsigned* const sched,
+                                                                                                     const int dephase) {
     constexpr int BN = 256, WAVES_N = 4;
     constexpr int NSTAGE = 4;
     constexpr int HKT = 64 / (int)sizeof(T);
@@ -90,6 +91,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(PP_NUM_SGPR))) 
     const int rounds = (ntiles + grid - 1) / grid;
     const int cnt_last = ntiles - (rounds - 1) * grid;
     const int my_tiles = rounds - 1 + (bid < cnt_last ? 1 : 0);
+    // De-phasing experiment (round 6, THEIA_PP_DEPHASE=<units of ~2k cycles>[+65536], default off; profiles/r06_dephase_experiment.txt):
+    // in a multi-round launch every CU is in its MFMA phase (chip at the power cap, HBM idle) and then in its store burst (MFMA idle)
+    // at the same time.  The workgroups that own one tile fewer than the others idle through the last round anyway: started late by
+    // part of a tile, their epilogues fall into the others' main loops at no cost to the launch.  +65536: every odd workgroup as well.
+    if (dephase != 0 && rounds > 1 && (my_tiles < rounds || ((dephase >> 16) & (bid & 1)))) {
+        for (int i = 0; i < (dephase & 0xffff); ++i) __builtin_amdgcn_s_sleep(32);
+    }
     // Schedule position -> tile (row block * tiles_n + column block).  panel == 0: row-major -- a round's 32 consecutive positions of an
     // XCD are ~32 / tiles_n row blocks x every column block: each activation row block enters one L2 once, and the XCD streams the
     // whole weight matrix every round.  That is the right trade while the weights fit in the 4 MB L2 beside the activation stream; for
@@ -636,8 +644,10 @@ static int pp_num_cus() {
 // launch needs no "last workgroup out" protocol, and the stream order makes the clear safe (every earlier launch of the stream has finished,
 // every later one starts behind it).  A launch recorded into a stream capture would replay with the counters of its first run: captured
 // launches use the static schedule.  THEIA_PP_DYNAMIC=0/1: off / on.
+#include <map>
 #include <mutex>
 #include <unordered_map>
+#include <utility>
 constexpr int PP_SCHED_BLOCKS = 4096, PP_SCHED_BLOCK_BYTES = 8 * 128;
 struct pp_sched_arena_t { unsigned char* base = nullptr; int next = 0; };
 static int pp_dynamic_mode() {
@@ -657,16 +667,32 @@ extern "C" int theia_set_gemm_schedule(int dynamic) {
     return prev;
 }
 #endif
+static int pp_device_xccs() {  // XCDs of the current device as a launch sees them (per device: the answer differs between partition modes)
+    static std::mutex mu;
+    static std::unordered_map<int, int> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(dev);
+    if (it != cache.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    cache[dev] = n;
+    return n;
+}
 static unsigned* pp_sched_block(hipStream_t stream) {
     static std::mutex mu;
-    static std::unordered_map<hipStream_t, pp_sched_arena_t> arenas;
+    // keyed by (device, stream): the null / per-thread stream handles are the same value on every device
+    static std::map<std::pair<int, hipStream_t>, pp_sched_arena_t> arenas;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
         return nullptr;
     }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     std::lock_guard<std::mutex> lock(mu);
-    pp_sched_arena_t& ar = arenas[stream];
+    pp_sched_arena_t& ar = arenas[std::make_pair(dev, stream)];
     if (ar.base == nullptr) {
         if (hipMalloc(reinterpret_cast<void**>(&ar.base), (size_t)PP_SCHED_BLOCKS * PP_SCHED_BLOCK_BYTES) != hipSuccess) {
             (void)hipGetLastError();
@@ -714,9 +740,18 @@ static int pp_launch_one(const theia_gemm_args_t* a, hipStream_t stream) {
     }
     // work-conserving schedule: any launch whose K gives the draw six half-tiles of lead
     const int nh = a->K / (64 / (int)sizeof(T));
-    const bool want_dyn = (g_pp_dynamic_override >= 0 ? g_pp_dynamic_override : pp_dynamic_mode()) != 0 && nh >= 8;
+    // ... on a device that exposes eight XCDs to a launch of at least eight workgroups: a workgroup only drains the queue of the XCD it
+    // runs on, so an XCD that receives no workgroup of the launch would leave its queue's tiles unwritten (CPX / DPX / QPX partitions,
+    // 4- or 6-XCD parts, grids below 8: the static schedule there).  A CU-masked stream that hides a whole XCD cannot be detected from
+    // here: do not combine CU masks with theia_set_gemm_schedule(1).
+    const bool want_dyn = (g_pp_dynamic_override >= 0 ? g_pp_dynamic_override : pp_dynamic_mode()) != 0 && nh >= 8 && grid >= 8 && pp_device_xccs() == 8;
     unsigned* sched = want_dyn ? pp_sched_block(stream) : nullptr;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, *a, tiles, panel, sched);
+    static int dephase = -1;
+    if (dephase < 0) {
+        const char* e = getenv("THEIA_PP_DEPHASE");
+        dephase = e != nullptr && atoi(e) > 0 ? atoi(e) : 0;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, *a, tiles, panel, sched, dephase);
     THEIA_CHECK_LAUNCH("theia_gemm_nt(pp)");
     return THEIA_OK;
 }

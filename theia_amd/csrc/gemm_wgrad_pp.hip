@@ -61,10 +61,16 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     const int ntile = tiles_n * mp.ntaps * tiles_c;
     // hardware places block b on XCD b % 8: give each XCD a contiguous range of (split, tile) so that the workgroups sharing a dY
     // column tile or an activation (tap, c) tile meet in one L2 (THEIA_WGRAD_XCD=0: A/B switch, plain order)
-    const int bid = plain_order ? (int)blockIdx.x : gt_xcd_remap(blockIdx.x, gridDim.x);
+    // Order inside a split (round 6): c tile slowest, then tap, then n tile.  The ~ntile / (8 / splits) consecutive tiles an XCD gets are
+    // then the taps and n tiles of ONE c tile: every tap of a 3x3 map gathers (a shifted copy of) the same activation pixels, so that
+    // c tile's slice of the gathered operand enters the L2 once instead of once per tap, beside the split's dense rows.  With the tap
+    // slowest (rounds 2-5; plain_order & 2: A/B switch THEIA_WGRAD_XCD=tap) an XCD held ~3 taps x every c tile: the stride-2 launches fetched
+    // 2.8 GB for ~1 GB of operands at 3.4 TB/s (profiles/r05_bench_pmc_traffic.json).
+    const int bid = (plain_order & 1) ? (int)blockIdx.x : gt_xcd_remap(blockIdx.x, gridDim.x);
     const int tile = bid % ntile, split = bid / ntile;
     const int tn = tile % tiles_n, tk = tile / tiles_n;
-    const int tap = tk / tiles_c, c0 = (tk - tap * tiles_c) * 256, n0 = tn * 256;
+    const int tap = (plain_order & 2) ? tk / tiles_c : tk % mp.ntaps;
+    const int c0 = ((plain_order & 2) ? tk - tap * tiles_c : tk / mp.ntaps) * 256, n0 = tn * 256;
     const int dy = mp.dy[tap], dx = mp.dx[tap];
 
     const int nsteps = (p.M + MS - 1) / MS;
@@ -393,7 +399,7 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
     static int plain_order = -1;
     if (plain_order < 0) {
         const char* e = getenv("THEIA_WGRAD_XCD");
-        plain_order = (e != nullptr && strcmp(e, "0") == 0) ? 1 : 0;
+        plain_order = e == nullptr ? 0 : strcmp(e, "0") == 0 ? 1 : strcmp(e, "tap") == 0 ? 2 : 0;
     }
     const int mode = theia_gemm_wgrad_pp_mode(a);
     const dim3 grid(tiles * a->splits);

@@ -706,8 +706,10 @@ constexpr int LOSS_CHUNK = 8192;
 static int loss_chunks(int64_t E) { return (int)((E + LOSS_CHUNK - 1) / LOSS_CHUNK); }
 extern "C" size_t theia_distill_loss_workspace_bytes(int b, int64_t E) { return (size_t)b * loss_chunks(E) * 5 * sizeof(float); }
 
-template <typename T>
-__global__ __launch_bounds__(256) void loss_partial_kernel(const T* __restrict__ pred, const float* __restrict__ target,
+// TQ: element type of the teacher features -- f32 (what the reference's loader hands over, data_utils.py:374-379: bf16 arithmetic, then
+// .float()) or those same values still in bf16 (identical results, 2 bytes less per element in each of the two passes)
+template <typename T, typename TQ = float>
+__global__ __launch_bounds__(256) void loss_partial_kernel(const T* __restrict__ pred, const TQ* __restrict__ target,
                                                            float* __restrict__ part, int64_t E, int nchunks) {
     __shared__ float red[5][4];
     const int sample = blockIdx.y, chunk = blockIdx.x;
@@ -792,23 +794,34 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     }
 }
 
-extern "C" int theia_distill_loss_fwd(const void* pred, const float* target, float* losses, float* coef, float* workspace,
-                                      int b, int64_t E, int dtype, void* stream) {
+extern "C" int theia_distill_loss_fwd_t(const void* pred, const void* target, int target_dtype, float* losses, float* coef, float* workspace,
+                                        int b, int64_t E, int dtype, void* stream) {
     THEIA_CHECK_ARG(pred && target && losses && coef && workspace, "theia_distill_loss_fwd: null pointer");
     THEIA_CHECK_ARG(b > 0 && E > 0 && E % 8 == 0, "theia_distill_loss_fwd: E must be a positive multiple of 8");
+    THEIA_CHECK_ARG(target_dtype == THEIA_F32 || (target_dtype == THEIA_BF16 && dtype == THEIA_BF16),
+                    "theia_distill_loss_fwd: targets are f32, or bf16 beside bf16 predictions (target_dtype %d, dtype %d)", target_dtype, dtype);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nch = loss_chunks(E);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(loss_partial_kernel<bf16_t>, dim3(nch, b), dim3(256), 0, s, (const bf16_t*)pred, target, workspace, E, nch),
-               hipLaunchKernelGGL(loss_partial_kernel<float>, dim3(nch, b), dim3(256), 0, s, (const float*)pred, target, workspace, E, nch),
-               "theia_distill_loss_fwd");
+    if (target_dtype == THEIA_BF16) {
+        hipLaunchKernelGGL((loss_partial_kernel<bf16_t, bf16_t>), dim3(nch, b), dim3(256), 0, s, (const bf16_t*)pred, (const bf16_t*)target, workspace, E, nch);
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((loss_partial_kernel<bf16_t, float>), dim3(nch, b), dim3(256), 0, s, (const bf16_t*)pred, (const float*)target, workspace, E, nch),
+                   hipLaunchKernelGGL((loss_partial_kernel<float, float>), dim3(nch, b), dim3(256), 0, s, (const float*)pred, (const float*)target, workspace, E, nch),
+                   "theia_distill_loss_fwd");
+    }
     THEIA_CHECK_LAUNCH("theia_distill_loss_fwd(partial)");
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, workspace, losses, coef, b, nch, E);
     THEIA_CHECK_LAUNCH("theia_distill_loss_fwd(finalize)");
     return THEIA_OK;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pred, const float* __restrict__ target,
+extern "C" int theia_distill_loss_fwd(const void* pred, const float* target, float* losses, float* coef, float* workspace,
+                                      int b, int64_t E, int dtype, void* stream) {
+    return theia_distill_loss_fwd_t(pred, target, THEIA_F32, losses, coef, workspace, b, E, dtype, stream);
+}
+
+template <typename T, typename TQ = float>
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pred, const TQ* __restrict__ target,
                                                        const float* __restrict__ coef, const float* __restrict__ w,
                                                        T* __restrict__ dpred, int b, int64_t E) {
     const int sample = blockIdx.y;
@@ -827,16 +840,27 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pre
     }
     store8(dpred + (int64_t)sample * E + e, o);
 }
-extern "C" int theia_distill_loss_bwd(const void* pred, const float* target, const float* coef, const float* w, void* dpred,
-                                      int b, int64_t E, int dtype, void* stream) {
+extern "C" int theia_distill_loss_bwd_t(const void* pred, const void* target, int target_dtype, const float* coef, const float* w, void* dpred,
+                                        int b, int64_t E, int dtype, void* stream) {
     THEIA_CHECK_ARG(pred && target && coef && w && dpred && b > 0 && E > 0 && E % 8 == 0, "theia_distill_loss_bwd: bad args");
+    THEIA_CHECK_ARG(target_dtype == THEIA_F32 || (target_dtype == THEIA_BF16 && dtype == THEIA_BF16),
+                    "theia_distill_loss_bwd: targets are f32, or bf16 beside bf16 predictions (target_dtype %d, dtype %d)", target_dtype, dtype);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((E / 8 + 255) / 256), b);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(loss_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)pred, target, coef, w, (bf16_t*)dpred, b, E),
-               hipLaunchKernelGGL(loss_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)pred, target, coef, w, (float*)dpred, b, E),
-               "theia_distill_loss_bwd");
+    if (target_dtype == THEIA_BF16) {
+        hipLaunchKernelGGL((loss_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)pred, (const bf16_t*)target, coef, w, (bf16_t*)dpred, b, E);
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((loss_bwd_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const bf16_t*)pred, (const float*)target, coef, w, (bf16_t*)dpred, b, E),
+                   hipLaunchKernelGGL((loss_bwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)pred, (const float*)target, coef, w, (float*)dpred, b, E),
+                   "theia_distill_loss_bwd");
+    }
     THEIA_CHECK_LAUNCH("theia_distill_loss_bwd");
     return THEIA_OK;
+}
+
+extern "C" int theia_distill_loss_bwd(const void* pred, const float* target, const float* coef, const float* w, void* dpred,
+                                      int b, int64_t E, int dtype, void* stream) {
+    return theia_distill_loss_bwd_t(pred, target, THEIA_F32, coef, w, dpred, b, E, dtype, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

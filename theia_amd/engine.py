@@ -988,8 +988,11 @@ class StudentEngine:
     # ================================================================== loss
     def distill_loss(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """-> f32[3] = (mse, cos, smooth_l1) of one teacher (models/rvfm.py:153-168)."""
-        if target.dtype != torch.float32:
-            raise TypeError("teacher features must be float32 (the reference feeds .float() tensors, train_rvfm.py:112-114)")
+        # float32 as the reference feeds them (.float() of bf16-normalised features, train_rvfm.py:112-114, data_utils.py:374-379) -- or
+        # those same values still in bf16 beside bf16 predictions: identical losses and gradients, 2 bytes less per element and pass
+        if target.dtype != torch.float32 and not (target.dtype == torch.bfloat16 and pred.dtype == torch.bfloat16):
+            raise TypeError("teacher features must be float32 (the reference feeds .float() tensors, train_rvfm.py:112-114), "
+                            "or bfloat16 for a bf16 / fp8 model")
         if pred.shape != target.shape:
             raise ValueError(f"prediction {tuple(pred.shape)} and target {tuple(target.shape)} shapes differ")
         target = target.to(pred.device).contiguous()

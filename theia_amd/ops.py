@@ -567,23 +567,23 @@ def attention_bwd(qkv, o, d_o, lse, b: int, n: int, h: int, ws: Optional[torch.T
 
 
 def distill_loss_fwd(pred: torch.Tensor, target: torch.Tensor, ws: Optional[torch.Tensor] = None):
-    """pred [b, E] (compute dtype), target [b, E] f32 -> (losses f32[3] = (mse, cos, l1), coef f32 [b,2])."""
+    """pred [b, E] (compute dtype), target [b, E] f32 (or bf16 beside bf16 predictions) -> (losses f32[3] = (mse, cos, l1), coef f32 [b,2])."""
     b, E = pred.shape
     losses = torch.empty(3, dtype=torch.float32, device=pred.device)
     coef = torch.empty(b, 2, dtype=torch.float32, device=pred.device)
     need = N.lib().theia_distill_loss_workspace_bytes(b, E) // 4
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.float32, device=pred.device)
-    N.check(N.lib().theia_distill_loss_fwd(pred.data_ptr(), target.data_ptr(), losses.data_ptr(), coef.data_ptr(), ws.data_ptr(),
-                                           b, E, _dt(pred), N.stream_ptr()), "theia_distill_loss_fwd")
+    N.check(N.lib().theia_distill_loss_fwd_t(pred.data_ptr(), target.data_ptr(), _dt(target), losses.data_ptr(), coef.data_ptr(), ws.data_ptr(),
+                                             b, E, _dt(pred), N.stream_ptr()), "theia_distill_loss_fwd")
     return losses, coef
 
 
 def distill_loss_bwd(pred: torch.Tensor, target: torch.Tensor, coef: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     b, E = pred.shape
     dpred = torch.empty_like(pred)
-    N.check(N.lib().theia_distill_loss_bwd(pred.data_ptr(), target.data_ptr(), coef.data_ptr(), w.data_ptr(), dpred.data_ptr(), b,
-                                           E, _dt(pred), N.stream_ptr()), "theia_distill_loss_bwd")
+    N.check(N.lib().theia_distill_loss_bwd_t(pred.data_ptr(), target.data_ptr(), _dt(target), coef.data_ptr(), w.data_ptr(), dpred.data_ptr(), b,
+                                             E, _dt(pred), N.stream_ptr()), "theia_distill_loss_bwd")
     return dpred
 
 
