@@ -193,6 +193,13 @@ int theia_wgrad_splits(int M, int N, int Ktot);
 /* the same for a multi-tap map: the kernel's 256 x 256 output tiles do not straddle taps, so a launch has kslots * ceil(in_c / 256) of them
  * per 256 output columns (in_c = 384: 2 per tap, the second one half used) */
 int theia_wgrad_splits_taps(int M, int N, int kslots, int in_c);
+/* v11: n <= 4 plain-matrix weight gradients (nn.Linear: rm_plain maps) with the same M in ONE launch, e.g. a layer's o_proj and fused
+ * q/k/v gradients (autograd of modeling_vit.py:207-238 under train_rvfm.py:125): 36 tiles x 7 M-splits instead of 9 x 28 and 27 x 9.
+ * Each problem carries its own splits (theia_wgrad_group_splits(M, total tiles) for all of them), slabs and bias_slabs and is finished
+ * with theia_wgrad_finish as after theia_gemm_wgrad.  Returns THEIA_ERR_UNSUPPORTED without launching anything when the problems do not
+ * qualify (not bf16, not plain matrices, n > 4): launch them one by one then. */
+int theia_gemm_wgrad_group(const theia_wgrad_args_t* probs, int n, int dtype, void* stream);
+int theia_wgrad_group_splits(int M, int tiles);
 
 /* out[n*sn + slot*ss + ci*sc] (+)= sum_s slab[s][n][slot*C + ci]   (f32; permutes into the PyTorch layout) */
 int theia_wgrad_reduce(const float* slabs, int splits, int N, int kslots, int C, float* out, int64_t sn,

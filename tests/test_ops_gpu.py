@@ -54,7 +54,7 @@ def rnd(x, dt):
 def test_library_loads_and_abi():
     from theia_amd import _native as N
     lib = N.lib()
-    assert lib.theia_abi_version() == N.ABI_VERSION == 10
+    assert lib.theia_abi_version() == N.ABI_VERSION == 11
     assert lib.theia_dtype_size(N.BF16) == 2
 
 
@@ -205,6 +205,35 @@ def test_linear_wgrad_and_colsum(dt, M, N, K):
     assert relerr(gb - 0.25, dyr.double().sum(0)) < 1e-5
     ops.linear_wgrad(wide[:, 64:], x.to(dev, dt), g2, accumulate=False, bias=(gb, False))
     assert relerr(gb, dyr.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,D", [(197 * 8, 768), (197 * 5 + 3, 384), (1000, 192), (700, 256)])
+def test_grouped_linear_wgrad_matches_the_single_launches(dt, M, D):
+    """theia_gemm_wgrad_group (ABI v11): the fused q/k/v gradient ([3D, D], a column slice of nothing -- dense) and o_proj's ([D, D]) in one
+    launch with one split count, each with its bias gradient, accumulation on / off per problem; f32 (no grouped kernel) takes the
+    one-by-one path through the same entry point.  Against f64, and against ops.linear_wgrad of each problem."""
+    from theia_amd import ops
+    dev = _dev()
+    dq, a = h((M, 3 * D), 21, 1.0), h((M, D), 22, 1.0)
+    dh, o = h((M, D), 23, 1.0), h((M, D), 24, 1.0)
+    tol = 1e-4 if dt == torch.float32 else 1e-3
+    probs, refs = [], []
+    for dy, x, acc in ((dq, a, False), (dh, o, True)):
+        dyr, xr = rnd(dy, dt), rnd(x, dt)
+        gw = torch.full((dy.shape[1], x.shape[1]), 0.5, dtype=torch.float32, device=dev)
+        gb = torch.full((dy.shape[1],), 0.25, dtype=torch.float32, device=dev)
+        probs.append((dy.to(dev, dt), x.to(dev, dt), gw, acc, (gb, acc)))
+        refs.append((dyr.t().double() @ xr.double() + (0.5 if acc else 0.0), dyr.double().sum(0) + (0.25 if acc else 0.0)))
+    ops.linear_wgrad_group(probs)
+    for (dy, x, gw, acc, (gb, _)), (rw, rb) in zip(probs, refs):
+        assert relerr(gw, rw) < tol, (dy.shape, relerr(gw, rw))
+        assert relerr(gb, rb) < 1e-5
+        g1 = torch.full_like(gw, 0.5)
+        b1 = torch.full_like(gb, 0.25)
+        ops.linear_wgrad(dy, x, g1, acc, bias=(b1, acc))
+        assert relerr(gw, g1) < (1e-6 if dt == torch.float32 else 2e-4)  # same products, another split of the f32 row sums
+        assert relerr(gb, b1) < 1e-6
 
 
 def _nhwc(a):

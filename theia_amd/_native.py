@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtheia_hip.so")
 
 F32, BF16, FP8 = 0, 1, 2
+ERR_UNSUPPORTED = -3  # THEIA_ERR_UNSUPPORTED
 ABI_VERSION = 11
 COMM_ID_BYTES = 128  # THEIA_COMM_ID_BYTES
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_MUL_DGELU, ACT_MUL_DRELU = 0, 1, 2, 3, 4
@@ -80,6 +81,8 @@ _SIGNATURES = {
     "theia_gemm_nt_tile": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "theia_gemm_nt_plan": (C.c_int, [C.POINTER(GemmArgs), C.c_int]),
     "theia_gemm_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_int, C.c_void_p]),
+    "theia_gemm_wgrad_group": (C.c_int, [C.POINTER(WgradArgs), C.c_int, C.c_int, C.c_void_p]),
+    "theia_wgrad_group_splits": (C.c_int, [C.c_int, C.c_int]),
     "theia_wgrad_fuses_bias": (C.c_int, [C.POINTER(WgradArgs), C.c_int]),
     "theia_wgrad_splits": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "theia_wgrad_splits_taps": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -639,6 +639,15 @@ extern "C" int theia_wgrad_splits_taps(int M, int N, int kslots, int in_c) {
 }
 extern "C" int theia_wgrad_splits(int M, int N, int Ktot) { return theia_wgrad_splits_taps(M, N, 1, Ktot); }
 
+// M-splits of a GROUPED launch (theia_gemm_wgrad_group): `tiles` = sum over its problems of ceil(N / 256) * ceil(in_c / 256), all with M rows
+extern "C" int theia_wgrad_group_splits(int M, int tiles) {
+    int s = theia_compute_cus() / (tiles > 0 ? tiles : 1);
+    const int smax = cdiv_i(M, 32) / 8;
+    if (s > smax) s = smax;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+}
+
 extern "C" int theia_gemm_wgrad_plan(const theia_wgrad_args_t* a, int dtype) {
     if (a == nullptr) return THEIA_ERR_INVALID;
     if (dtype == THEIA_BF16 && wgrad_use_pp() && theia_gemm_wgrad_pp_supported(a)) return 100 + theia_gemm_wgrad_pp_mode(a);
@@ -649,7 +658,7 @@ extern "C" int theia_wgrad_fuses_bias(const theia_wgrad_args_t* a, int dtype) {
     return a != nullptr && dtype == THEIA_BF16 && wgrad_use_pp() && theia_gemm_wgrad_pp_supported(a) ? 1 : 0;
 }
 
-extern "C" int theia_gemm_wgrad(const theia_wgrad_args_t* a, int dtype, void* stream) {
+static int wgrad_check_args(const theia_wgrad_args_t* a, int dtype) {
     THEIA_CHECK_ARG(a != nullptr, "theia_gemm_wgrad: null args");
     THEIA_CHECK_ARG(a->bias_out == nullptr || (a->bias_slabs != nullptr && theia_wgrad_fuses_bias(a, dtype)),
                     "theia_gemm_wgrad: bias_out needs bias_slabs and a kernel that fuses it (theia_wgrad_fuses_bias)");
@@ -663,7 +672,28 @@ extern "C" int theia_gemm_wgrad(const theia_wgrad_args_t* a, int dtype, void* st
                     "theia_gemm_wgrad: pitches/offsets must be multiples of 8 elements");
     for (int t = 0; t < a->map.ntaps; ++t)
         THEIA_CHECK_ARG(a->map.wslot[t] >= 0 && a->map.wslot[t] < a->kslots, "theia_gemm_wgrad: wslot out of range");
-    int rc = check_rowmap(a->map, 64, "theia_gemm_wgrad");
+    return check_rowmap(a->map, 64, "theia_gemm_wgrad");
+}
+
+// n plain-matrix weight gradients (nn.Linear: one tap, one row per "image") in ONE launch of the ping-pong kernel -- see
+// gemm_wgrad_pp.hip "Grouped launch".  Every problem carries its own splits / slabs / bias_slabs exactly as for theia_gemm_wgrad and is
+// finished the same way (theia_wgrad_finish per problem).  THEIA_ERR_UNSUPPORTED (nothing launched): not bf16, the ping-pong kernel is
+// switched off, n > 4, or a problem that is not a plain matrix -- the caller launches them one by one.
+int theia_gemm_wgrad_pp_group_launch(const theia_wgrad_args_t* a, int n, hipStream_t stream);
+extern "C" int theia_gemm_wgrad_group(const theia_wgrad_args_t* probs, int n, int dtype, void* stream) {
+    THEIA_CHECK_ARG(probs != nullptr && n >= 1, "theia_gemm_wgrad_group: no problems");
+    for (int k = 0; k < n; ++k) {
+        const int rc = wgrad_check_args(&probs[k], dtype);
+        if (rc) return rc;
+    }
+    if (dtype != THEIA_BF16 || !wgrad_use_pp()) return THEIA_ERR_UNSUPPORTED;
+    for (int k = 0; k < n; ++k)
+        if (!theia_gemm_wgrad_pp_supported(&probs[k])) return THEIA_ERR_UNSUPPORTED;
+    return theia_gemm_wgrad_pp_group_launch(probs, n, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int theia_gemm_wgrad(const theia_wgrad_args_t* a, int dtype, void* stream) {
+    int rc = wgrad_check_args(a, dtype);
     if (rc) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == THEIA_BF16 && wgrad_use_pp()) {

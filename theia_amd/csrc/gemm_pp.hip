@@ -96,7 +96,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(PP_NUM_SGPR))) 
     // at the same time.  The workgroups that own one tile fewer than the others idle through the last round anyway: started late by
     // part of a tile, their epilogues fall into the others' main loops at no cost to the launch.  +65536: every odd workgroup as well.
     if (dephase != 0 && rounds > 1 && (my_tiles < rounds || ((dephase >> 16) & (bid & 1)))) {
-        for (int i = 0; i < (dephase & 0xffff); ++i) __builtin_amdgcn_s_sleep(32);
+        int units = dephase & 0xffff;
+        if ((dephase >> 17) & 1) units = my_tiles < rounds ? 1 + ((bid - cnt_last) * units) / (grid - cnt_last) : units;  // +131072: spread over (0, units]
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(32);
     }
     // Schedule position -> tile (row block * tiles_n + column block).  panel == 0: row-major -- a round's 32 consecutive positions of an
     // XCD are ~32 / tiles_n row blocks x every column block: each activation row block enters one L2 once, and the XCD streams the

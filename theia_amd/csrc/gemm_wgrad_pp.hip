@@ -44,8 +44,10 @@ __device__ __forceinline__ uint4 wp_tr_frag(const char* __restrict__ part, int l
 //      repeats with that period: each staged row carries a bit mask built once and the loop tests one bit of it
 // Measured (profiles/r03_ab_wgrad_row_modes.txt): the ~35 VALU instructions per staged row of mode 0 sit in the R / M segments of every
 // half-step; mode 1 took 19 % off the ViT weight-gradient launches.
-template <bool FAST, bool SPLIT_ISSUE = true, int NSTAGE = 4, int MODE = 0>
-__global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_args_t p, const int plain_order) {
+// The body of one workgroup: (tile, split) number `hw_bid` of the `nblocks` of problem p.  hw_bid % 8 must be the XCD the hardware put the
+// workgroup on (a launch's own blockIdx.x, or an index into a block range that starts at a multiple of 8: the grouped launch below).
+template <bool FAST, bool SPLIT_ISSUE, int NSTAGE, int MODE>
+__device__ __forceinline__ void wgrad_pp_body(const theia_wgrad_args_t& p, const int plain_order, const int hw_bid, const int nblocks) {
     constexpr bool wgrad_split_issue = SPLIT_ISSUE;
     constexpr int MS = 32, ROWB = 512, PART = MS * ROWB, STAGE = 2 * PART;
     constexpr int AHEAD = NSTAGE - 1;  // half-steps in flight ahead of the one being multiplied; 4 LDS-DMA operations per thread each
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     // c tile's slice of the gathered operand enters the L2 once instead of once per tap, beside the split's dense rows.  With the tap
     // slowest (rounds 2-5; plain_order & 2: A/B switch THEIA_WGRAD_XCD=tap) an XCD held ~3 taps x every c tile: the stride-2 launches fetched
     // 2.8 GB for ~1 GB of operands at 3.4 TB/s (profiles/r05_bench_pmc_traffic.json).
-    const int bid = (plain_order & 1) ? (int)blockIdx.x : gt_xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = (plain_order & 1) ? hw_bid : gt_xcd_remap(hw_bid, nblocks);
     const int tile = bid % ntile, split = bid / ntile;
     const int tn = tile % tiles_n, tk = tile / tiles_n;
     const int tap = (plain_order & 2) ? tk / tiles_c : tk % mp.ntaps;
@@ -324,6 +326,35 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
     }
 }
 
+template <bool FAST, bool SPLIT_ISSUE = true, int NSTAGE = 4, int MODE = 0>
+__global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_args_t p, const int plain_order) {
+    wgrad_pp_body<FAST, SPLIT_ISSUE, NSTAGE, MODE>(p, plain_order, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Grouped launch (round 6): up to WGRAD_GROUP_MAX plain-matrix problems (mode 1: the nn.Linear weight gradients) in ONE grid.  Why: a
+// launch wants one workgroup per CU, so the M-split count of a problem is CUs / tiles -- 28 for the 9 tiles of a [768, 768] gradient
+// (o_proj), each split 900 rows long: 28 prologues, 28 f32 partials of every tile to write and to reduce again (66 MB for a 2.4 MB
+// result), 713 TFLOP/s against 1.0-1.07 PFLOP/s for the 27 / 36-tile gradients.  o_proj's and the fused q/k/v gradient of a layer share M
+// and are both at hand when the attention backward has run: together they are 36 tiles x 7 splits of 3602 rows -- the same shape of
+// launch as fc1's and fc2's.  Block ranges start at multiples of 8 (the XCD of a workgroup is blockIdx.x % 8 whatever the problem).
+constexpr int WGRAD_GROUP_MAX = 4;
+struct wgrad_group_t {
+    int nprob;
+    int first[WGRAD_GROUP_MAX];   // first block of problem k (a multiple of 8)
+    int count[WGRAD_GROUP_MAX];   // its tiles x splits
+    theia_wgrad_args_t prob[WGRAD_GROUP_MAX];
+};
+template <int NSTAGE>
+__global__ __launch_bounds__(512) void gemm_wgrad_pp_group_kernel(const wgrad_group_t g, const int plain_order) {
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < WGRAD_GROUP_MAX; ++i)
+        if (i < g.nprob && (int)blockIdx.x >= g.first[i]) k = i;
+    const int local = (int)blockIdx.x - g.first[k];
+    if (local >= g.count[k]) return;  // (padding up to the next multiple of 8)
+    wgrad_pp_body<true, true, NSTAGE, 1>(g.prob[k], plain_order, local, g.count[k]);
+}
+
 // out[n] (+)= sum_s part[s*N + n], fixed order
 __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __restrict__ part, int splits, int N, float* __restrict__ out,
                                                                 int accumulate) {
@@ -370,6 +401,55 @@ int theia_gemm_wgrad_pp_mode(const theia_wgrad_args_t* a) {
     return 10;
 }
 
+static int wgrad_plain_order() {
+    static int plain_order = -1;
+    if (plain_order < 0) {
+        const char* e = getenv("THEIA_WGRAD_XCD");
+        plain_order = e == nullptr ? 0 : strcmp(e, "0") == 0 ? 1 : strcmp(e, "tap") == 0 ? 2 : 0;
+    }
+    return plain_order;
+}
+
+// n <= WGRAD_GROUP_MAX plain-matrix problems (theia_gemm_wgrad_pp_mode == 11 each) in one launch; THEIA_ERR_UNSUPPORTED otherwise.
+int theia_gemm_wgrad_pp_group_launch(const theia_wgrad_args_t* a, int n, hipStream_t stream) {
+    if (n < 1 || n > WGRAD_GROUP_MAX) return THEIA_ERR_UNSUPPORTED;
+    wgrad_group_t g;
+    g.nprob = n;
+    int next = 0;
+    for (int k = 0; k < WGRAD_GROUP_MAX; ++k) {
+        g.first[k] = next;
+        g.count[k] = 0;
+        if (k >= n) continue;
+        if (theia_gemm_wgrad_pp_mode(&a[k]) != 11) return THEIA_ERR_UNSUPPORTED;
+        g.prob[k] = a[k];
+        g.count[k] = cdiv_i(a[k].N, 256) * cdiv_i(a[k].map.in_c, 256) * a[k].splits;
+        next = (next + g.count[k] + 7) & ~7;
+    }
+    constexpr int lds4 = 4 * 2 * 32 * 512, lds5 = 5 * 2 * 32 * 512;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_group_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_group_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds5);
+        attr_set = true;
+    }
+    static int stages = -1;
+    if (stages < 0) {
+        const char* e = getenv("THEIA_WGRAD_STAGES");
+        stages = e != nullptr && atoi(e) == 5 ? 5 : 4;
+    }
+    const dim3 grid(g.first[n - 1] + g.count[n - 1]);
+    if (stages == 5) hipLaunchKernelGGL(gemm_wgrad_pp_group_kernel<5>, grid, dim3(512), lds5, stream, g, wgrad_plain_order());
+    else hipLaunchKernelGGL(gemm_wgrad_pp_group_kernel<4>, grid, dim3(512), lds4, stream, g, wgrad_plain_order());
+    THEIA_CHECK_LAUNCH("theia_gemm_wgrad_group(pp)");
+    for (int k = 0; k < n; ++k)
+        if (a[k].bias_out != nullptr && a[k].defer_bias_reduce == 0) {
+            hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3(cdiv_i(a[k].N, 256)), dim3(256), 0, stream, a[k].bias_slabs, a[k].splits, a[k].N,
+                               a[k].bias_out, a[k].bias_accumulate);
+            THEIA_CHECK_LAUNCH("theia_gemm_wgrad_group(pp bias)");
+        }
+    return THEIA_OK;
+}
+
 // bf16 only; requires in_c % 64 == 0.  Returns THEIA_ERR_UNSUPPORTED when the shape does not qualify.
 int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) {
     if (!theia_gemm_wgrad_pp_supported(a)) return THEIA_ERR_UNSUPPORTED;
@@ -396,11 +476,7 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
         const char* e = getenv("THEIA_WGRAD_ISSUE");
         issue_in_m = (e != nullptr && strcmp(e, "m") == 0) ? 1 : 0;
     }
-    static int plain_order = -1;
-    if (plain_order < 0) {
-        const char* e = getenv("THEIA_WGRAD_XCD");
-        plain_order = e == nullptr ? 0 : strcmp(e, "0") == 0 ? 1 : strcmp(e, "tap") == 0 ? 2 : 0;
-    }
+    const int plain_order = wgrad_plain_order();
     const int mode = theia_gemm_wgrad_pp_mode(a);
     const dim3 grid(tiles * a->splits);
     if (mode == 11 && stages == 5) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 5, 1>), grid, dim3(512), lds5, stream, *a, plain_order);

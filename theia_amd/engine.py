@@ -648,7 +648,9 @@ class StudentEngine:
             raise TypeError(f"gradient dtype {dz.dtype} does not match the engine's compute dtype {T}")
         wsz = max(N.lib().theia_layernorm_bwd_workspace_bytes(M, D) // 4, N.lib().theia_colsum_workspace_bytes(M, F) // 4,
                   N.lib().theia_colsum_workspace_bytes(b, NTOK * D) // 4,
-                  max(ops.wgrad_splits(M, n_, k_) * n_ * (k_ + 1) for n_, k_ in ((D, F), (F, D), (D, D), (3 * D, D), (D, 768))))  # slabs + bias partials
+                  max(ops.wgrad_splits(M, n_, k_) * n_ * (k_ + 1) for n_, k_ in ((D, F), (F, D), (D, D), (3 * D, D), (D, 768))),  # slabs + bias partials
+                  # the grouped q/k/v + o_proj launch: one split count for both problems
+                  N.lib().theia_wgrad_group_splits(M, (-(-3 * D // 256) + -(-D // 256)) * -(-D // 256)) * 4 * D * (D + 1))
         ws = self.ws(wsz, dev)
         side = self._side_queue(dev, wsz)
 
@@ -679,13 +681,14 @@ class StudentEngine:
             del dpre
             dh1 = self._ln_bwd(dm, h1, L.layernorm_after, mean2, rstd2, dh, ws)
             del dm, dh
-            # h1 = h + o_proj(o)
-            wgrad(dh1, o, L.attention.o_proj.weight, L.attention.o_proj.bias)
+            # h1 = h + o_proj(o).  Its weight gradient ([D, D]: 9 output tiles, i.e. 28 M-splits alone) waits for the q/k/v gradient and
+            # shares that launch (36 tiles x 7 splits; ops.linear_wgrad_group); alone only when the fused q/k/v path is not taken
             do = self._mm(dh1, f"l{i}.woT")
             dqkv = ops.attention_bwd(qkv, o, do, lse, b, NTOK, nh, ws)
             del do
             qkv_mods = (L.attention.q_proj, L.attention.k_proj, L.attention.v_proj)
-            if not self._wgrad_qkv_fused(dqkv, a, qkv_mods, side):
+            if not self._wgrad_qkv_fused(dqkv, a, qkv_mods, side, also=(dh1, o, L.attention.o_proj)):
+                wgrad(dh1, o, L.attention.o_proj.weight, L.attention.o_proj.bias)
                 for j, prj in enumerate(qkv_mods):
                     sl = dqkv[:, j * D:(j + 1) * D]
                     wgrad(sl, a, prj.weight, prj.bias)
@@ -752,12 +755,13 @@ class StudentEngine:
             accw = accb = True
         return ops.layernorm_bwd(dy, x, ln.weight, mean, rstd, dresid, gw, gb, accw, ws)
 
-    def _wgrad_qkv_fused(self, dqkv: torch.Tensor, a: torch.Tensor, mods, side: "_SideQueue") -> bool:
+    def _wgrad_qkv_fused(self, dqkv: torch.Tensor, a: torch.Tensor, mods, side: "_SideQueue", also=None) -> bool:
         """The q / k / v weight and bias gradients as ONE [3D, D] weight-gradient GEMM when their slots in the flat gradient bucket
         are adjacent (they are: consecutive parameters of one layer, D*D and D multiples of 8): 27 output tiles x 9 row splits
         instead of 3 x (9 tiles x 28 splits) -- a third of the f32 slab traffic (64 MB instead of 198 MB per layer, written and
         read back) and a third of the launches.  Returns False (caller falls back to three GEMMs) when a slot is frozen or the
-        slots are not adjacent."""
+        slots are not adjacent.  also = (dy, x, linear): one more nn.Linear with the same M whose gradients join the launch (round 6:
+        o_proj -- ops.linear_wgrad_group; THEIA_WGRAD_GROUP=0: A/B switch, two launches)."""
         D = self.D
         ws_, bs_ = [m.weight for m in mods], [m.bias for m in mods]
         if not all(p.requires_grad for p in ws_ + bs_) or os.environ.get("THEIA_QKV_WGRAD") == "split":
@@ -788,6 +792,15 @@ class StudentEngine:
         acc = gw[0][1]
         gw_all = torch.as_strided(gw[0][0], (3 * D, D), (D, 1))   # views over the three adjacent bucket slots
         gb_all = torch.as_strided(gb[0][0], (3 * D,), (1,))
+        if also is not None and (also[2].weight.requires_grad or also[2].bias.requires_grad):
+            dy2, x2, lin = also
+            gw2, accw2 = self._grad(lin.weight)
+            gb2, accb2 = self._grad(lin.bias)
+            if lin.weight.requires_grad and lin.bias.requires_grad and os.environ.get("THEIA_WGRAD_GROUP", "1") != "0":
+                side.run(lambda: ops.linear_wgrad_group([(dqkv, a, gw_all, acc, (gb_all, acc)), (dy2, x2, gw2, accw2, (gb2, accb2))], side.ws),
+                         dqkv, a, dy2, x2)
+                return True
+            side.run(lambda: ops.linear_wgrad(dy2, x2, gw2, accw2, side.ws, bias=(gb2, accb2)), dy2, x2)
         side.run(lambda: ops.linear_wgrad(dqkv, a, gw_all, acc, side.ws, bias=(gb_all, acc)), dqkv, a)
         return True
 

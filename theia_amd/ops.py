@@ -363,6 +363,56 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, grad_w: torch.Tensor, accumu
         colsum(dy, bias[0], bias[1], ws)
 
 
+def linear_wgrad_group(problems, ws: Optional[torch.Tensor] = None) -> None:
+    """The weight and bias gradients of several nn.Linear layers that share M, as ONE weight-gradient launch (theia_gemm_wgrad_group: the
+    split count is CUs / (all their tiles), so a small problem no longer runs 28 splits of its own) + one slab reduction each.
+    problems: [(dy [M, N_i], x [M, K_i], grad_w [N_i, K_i] f32, accumulate, (grad_b, accumulate))].  Falls back to linear_wgrad per
+    problem when the library does not take the group (f32 parity mode, narrow shapes)."""
+    M = problems[0][0].shape[0]
+    ok = _dt(problems[0][0]) == N.BF16 and len(problems) <= 4 and all(dy.shape[0] == M and dy.dtype == problems[0][0].dtype
+                                                                      for dy, *_ in problems)
+    if ok:
+        tiles = sum(-(-dy.shape[1] // 256) * -(-x.shape[1] // 256) for dy, x, *_ in problems)
+        splits = N.lib().theia_wgrad_group_splits(M, tiles)
+        need = sum(splits * dy.shape[1] * (x.shape[1] + 1) for dy, x, *_ in problems)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.float32, device=problems[0][0].device)
+        arr = (N.WgradArgs * len(problems))()
+        parts = []
+        off = 0
+        for i, (dy, x, gw, accw, (gb, accb)) in enumerate(problems):
+            Nn, K = dy.shape[1], x.shape[1]
+            slabs = ws[off:off + splits * Nn * K]
+            bslabs = ws[off + splits * Nn * K:off + splits * Nn * (K + 1)]
+            off += splits * Nn * (K + 1)
+            g = _wgrad_args(dy, x, slabs, M, Nn, dy.stride(0), 1, splits, rm_plain(K, x.stride(0), dy.stride(0)))
+            if not N.lib().theia_wgrad_fuses_bias(g, _dt(dy)):
+                ok = False
+                break
+            g.bias_slabs, g.bias_out, g.bias_accumulate, g.defer_bias_reduce = bslabs.data_ptr(), gb.data_ptr(), int(accb), 1
+            arr[i] = g
+            parts.append((slabs, bslabs, Nn, K, gw, accw, gb, accb))
+    if ok:
+        e0 = e1 = None
+        if WGRAD_PROFILE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        rc = N.lib().theia_gemm_wgrad_group(arr, len(problems), _dt(problems[0][0]), N.stream_ptr())
+        if e0 is not None:
+            e1.record()
+        if rc == 0:
+            if e0 is not None:
+                WGRAD_PROFILE.append((e0, e1, sum(2.0 * M * q[2] * q[3] for q in parts), f"s{splits}g{len(parts)}",
+                                      (M, sum(q[2] for q in parts), parts[0][3])))
+            for slabs, bslabs, Nn, K, gw, accw, gb, accb in parts:
+                wgrad_finish(slabs, splits, Nn, 1, K, gw, K, 0, 1, accw, (bslabs, gb, accb))
+            return
+        if rc != N.ERR_UNSUPPORTED:
+            N.check(rc, "theia_gemm_wgrad_group")
+    for dy, x, gw, accw, bias in problems:
+        linear_wgrad(dy, x, gw, accw, ws, bias=bias)
+
+
 def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool, ws: Optional[torch.Tensor] = None) -> None:
     M, Nn = x.shape
     need = N.lib().theia_colsum_workspace_bytes(M, Nn) // 4
