@@ -91,15 +91,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(PP_NUM_SGPR))) 
     const int rounds = (ntiles + grid - 1) / grid;
     const int cnt_last = ntiles - (rounds - 1) * grid;
     const int my_tiles = rounds - 1 + (bid < cnt_last ? 1 : 0);
-    // De-phasing experiment (round 6, THEIA_PP_DEPHASE=<units of ~2k cycles>[+65536], default off; profiles/r06_dephase_experiment.txt):
-    // in a multi-round launch every CU is in its MFMA phase (chip at the power cap, HBM idle) and then in its store burst (MFMA idle)
-    // at the same time.  The workgroups that own one tile fewer than the others idle through the last round anyway: started late by
-    // part of a tile, their epilogues fall into the others' main loops at no cost to the launch.  +65536: every odd workgroup as well.
-    if (dephase != 0 && rounds > 1 && (my_tiles < rounds || ((dephase >> 16) & (bid & 1)))) {
-        int units = dephase & 0xffff;
-        if ((dephase >> 17) & 1) units = my_tiles < rounds ? 1 + ((bid - cnt_last) * units) / (grid - cnt_last) : units;  // +131072: spread over (0, units]
-        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(32);
-    }
     // Schedule position -> tile (row block * tiles_n + column block).  panel == 0: row-major -- a round's 32 consecutive positions of an
     // XCD are ~32 / tiles_n row blocks x every column block: each activation row block enters one L2 once, and the XCD streams the
     // whole weight matrix every round.  That is the right trade while the weights fit in the 4 MB L2 beside the activation stream; for
@@ -131,6 +122,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(PP_NUM_SGPR))) 
     // keeping issue and wait in one straight-line block (a second copy of the M segment) cost 700 spills.
     // A launch degrades in proportion to the CUs it actually gets; a workgroup that finds its queue empty leaves.
     const bool dyn = sched != nullptr;
+    // De-phasing (round 6; THEIA_PP_DEPHASE=0: off, =<units of ~2k cycles>[+65536][+131072]: forced; profiles/r06_dephase_experiment.txt):
+    // in a multi-round launch every CU is in its MFMA phase (chip at the power cap, HBM idle) and then in its store burst (MFMA idle)
+    // at the same time.  The workgroups that own one tile fewer than the others idle through the last round anyway: started late by
+    // part of a tile (spread over (0, units], the host's estimate of 2/3 of a tile), their epilogues fall into the others' main loops
+    // at no cost to the launch: fc2 data-gradient 171-181 -> 166-170 us, fc1 forward 166-170 -> 164-167, the step -0.15 ms; the
+    // result is unaffected (same tiles, same order of additions).  +65536 (every odd workgroup as well: costs more than it gains).
+    if (dephase != 0 && !dyn && rounds > 1 && (my_tiles < rounds || ((dephase >> 16) & (bid & 1)))) {
+        int units = dephase & 0xffff;
+        if ((dephase >> 17) & 1) units = my_tiles < rounds ? 1 + ((bid - cnt_last) * units) / (grid - cnt_last) : units;  // +131072: spread over (0, units]
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     int xcc = 0;
     if (dyn) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -748,10 +750,16 @@ static int pp_launch_one(const theia_gemm_args_t* a, hipStream_t stream) {
     // here: do not combine CU masks with theia_set_gemm_schedule(1).
     const bool want_dyn = (g_pp_dynamic_override >= 0 ? g_pp_dynamic_override : pp_dynamic_mode()) != 0 && nh >= 8 && grid >= 8 && pp_device_xccs() == 8;
     unsigned* sched = want_dyn ? pp_sched_block(stream) : nullptr;
-    static int dephase = -1;
-    if (dephase < 0) {
+    static int dephase_env = -2;  // -1: automatic
+    if (dephase_env == -2) {
         const char* e = getenv("THEIA_PP_DEPHASE");
-        dephase = e != nullptr && atoi(e) > 0 ? atoi(e) : 0;
+        dephase_env = e == nullptr ? -1 : atoi(e) > 0 ? atoi(e) : 0;
+    }
+    int dephase = dephase_env;
+    if (dephase < 0) {  // ~2/3 of a tile's duration in units of 2048 cycles: ~1400 cycles per half k-tile of a 256-row tile + ~12k of tile switch and epilogue
+        const long cyc = (long)nh * 1400 * BM / 256 + 12000;
+        const int units = (int)(cyc * 2 / 3 / 2048);
+        dephase = tiles > grid ? 131072 + (units < 1 ? 1 : units > 24 ? 24 : units) : 0;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, *a, tiles, panel, sched, dephase);
     THEIA_CHECK_LAUNCH("theia_gemm_nt(pp)");
