@@ -650,7 +650,10 @@ class StudentEngine:
                   N.lib().theia_colsum_workspace_bytes(b, NTOK * D) // 4,
                   max(ops.wgrad_splits(M, n_, k_) * n_ * (k_ + 1) for n_, k_ in ((D, F), (F, D), (D, D), (3 * D, D), (D, 768))),  # slabs + bias partials
                   # the grouped q/k/v + o_proj launch: one split count for both problems
-                  N.lib().theia_wgrad_group_splits(M, (-(-3 * D // 256) + -(-D // 256)) * -(-D // 256)) * 4 * D * (D + 1))
+                  N.lib().theia_wgrad_group_splits(M, (-(-3 * D // 256) + -(-D // 256)) * -(-D // 256)) * 4 * D * (D + 1),
+                  # ... and with fc1 / fc2 in it (the small students)
+                  N.lib().theia_wgrad_group_splits(M, (-(-3 * D // 256) + -(-D // 256)) * -(-D // 256) + 2 * -(-F // 256) * -(-D // 256))
+                  * (4 * D * (D + 1) + F * (D + 1) + D * (F + 1)))
         ws = self.ws(wsz, dev)
         side = self._side_queue(dev, wsz)
 
@@ -664,6 +667,21 @@ class StudentEngine:
             gb_, accb_ = self._grad(pb)
             side.run(lambda: ops.linear_wgrad(dy, x, gw_, accw_, side.ws, bias=(gb_, accb_)), dy, x)
 
+        # Grouped launches (ops.linear_wgrad_group): a layer's o_proj gradient always waits for the fused q/k/v gradient and shares its
+        # launch; when ALL FOUR weight gradients of a layer are few tiles (DeiT-small: 38, DeiT-tiny: 10 -- a launch of their own each
+        # would be 4-64 M-splits of a handful of tiles, 30-70 us apiece), fc2's and fc1's wait as well: one launch per layer.  DeiT-base
+        # (108 tiles = 2 splits on 216 of 256 CUs) keeps fc1 / fc2 on their own 36 x 7 launches.  THEIA_WGRAD_GROUP=0 / 1 / all: A/B.
+        tl = lambda n_, k_: -(-n_ // 256) * -(-k_ // 256)
+        gmode = os.environ.get("THEIA_WGRAD_GROUP", "auto")
+        group_all = T == torch.bfloat16 and (gmode == "all" or (gmode == "auto" and tl(3 * D, D) + tl(D, D) + tl(F, D) + tl(D, F) <= 64))
+        pending: List[Tuple[torch.Tensor, torch.Tensor, Any]] = []
+
+        def wgrad_later(dy, x, lin):
+            if group_all and lin.weight.requires_grad and lin.bias.requires_grad:
+                pending.append((dy, x, lin))
+            else:
+                wgrad(dy, x, lin.weight, lin.bias)
+
         hL, meanf, rstdf = saved["final"]
         dh = self._ln_bwd(dz, hL, vit.layernorm, meanf, rstdf, None, ws)
         vit_buckets = [bk for bk in self.buckets if bk.name.startswith("vit:")]  # layer groups 9-11, 6-8, 3-5, then 2, 1, 0 (+ embeddings)
@@ -673,10 +691,10 @@ class StudentEngine:
             (h, mean1, rstd1, a, qkv, o, lse, h1, mean2, rstd2, m, pre, act) = saved["layers"][i]
             saved["layers"][i] = None
             # h2 = h1 + fc2(act)
-            wgrad(dh, act, L.mlp.fc2.weight, L.mlp.fc2.bias)
+            wgrad_later(dh, act, L.mlp.fc2)
             dpre = self._mm(dh, f"l{i}.w2T", None, act=N.ACT_MUL_DGELU, aux_in=pre)
             del act, pre
-            wgrad(dpre, m, L.mlp.fc1.weight, L.mlp.fc1.bias)
+            wgrad_later(dpre, m, L.mlp.fc1)
             dm = self._mm(dpre, f"l{i}.w1T")
             del dpre
             dh1 = self._ln_bwd(dm, h1, L.layernorm_after, mean2, rstd2, dh, ws)
@@ -687,8 +705,11 @@ class StudentEngine:
             dqkv = ops.attention_bwd(qkv, o, do, lse, b, NTOK, nh, ws)
             del do
             qkv_mods = (L.attention.q_proj, L.attention.k_proj, L.attention.v_proj)
-            if not self._wgrad_qkv_fused(dqkv, a, qkv_mods, side, also=(dh1, o, L.attention.o_proj)):
-                wgrad(dh1, o, L.attention.o_proj.weight, L.attention.o_proj.bias)
+            also = [(dh1, o, L.attention.o_proj)] + pending
+            pending = []
+            if not self._wgrad_qkv_fused(dqkv, a, qkv_mods, side, also=also):
+                for dy_, x_, lin_ in also:
+                    wgrad(dy_, x_, lin_.weight, lin_.bias)
                 for j, prj in enumerate(qkv_mods):
                     sl = dqkv[:, j * D:(j + 1) * D]
                     wgrad(sl, a, prj.weight, prj.bias)
@@ -760,8 +781,8 @@ class StudentEngine:
         are adjacent (they are: consecutive parameters of one layer, D*D and D multiples of 8): 27 output tiles x 9 row splits
         instead of 3 x (9 tiles x 28 splits) -- a third of the f32 slab traffic (64 MB instead of 198 MB per layer, written and
         read back) and a third of the launches.  Returns False (caller falls back to three GEMMs) when a slot is frozen or the
-        slots are not adjacent.  also = (dy, x, linear): one more nn.Linear with the same M whose gradients join the launch (round 6:
-        o_proj -- ops.linear_wgrad_group; THEIA_WGRAD_GROUP=0: A/B switch, two launches)."""
+        slots are not adjacent.  also = [(dy, x, linear)]: more nn.Linear layers with the same M whose gradients join the launch (round 6:
+        o_proj, for the small students fc2 and fc1 too -- ops.linear_wgrad_group; THEIA_WGRAD_GROUP=0: A/B switch, one launch each)."""
         D = self.D
         ws_, bs_ = [m.weight for m in mods], [m.bias for m in mods]
         if not all(p.requires_grad for p in ws_ + bs_) or os.environ.get("THEIA_QKV_WGRAD") == "split":
@@ -792,16 +813,21 @@ class StudentEngine:
         acc = gw[0][1]
         gw_all = torch.as_strided(gw[0][0], (3 * D, D), (D, 1))   # views over the three adjacent bucket slots
         gb_all = torch.as_strided(gb[0][0], (3 * D,), (1,))
-        if also is not None and (also[2].weight.requires_grad or also[2].bias.requires_grad):
-            dy2, x2, lin = also
+        probs = [(dqkv, a, gw_all, acc, (gb_all, acc))]
+        for dy2, x2, lin in (also or []):
+            if not (lin.weight.requires_grad or lin.bias.requires_grad):
+                continue
             gw2, accw2 = self._grad(lin.weight)
             gb2, accb2 = self._grad(lin.bias)
-            if lin.weight.requires_grad and lin.bias.requires_grad and os.environ.get("THEIA_WGRAD_GROUP", "1") != "0":
-                side.run(lambda: ops.linear_wgrad_group([(dqkv, a, gw_all, acc, (gb_all, acc)), (dy2, x2, gw2, accw2, (gb2, accb2))], side.ws),
-                         dqkv, a, dy2, x2)
-                return True
-            side.run(lambda: ops.linear_wgrad(dy2, x2, gw2, accw2, side.ws, bias=(gb2, accb2)), dy2, x2)
-        side.run(lambda: ops.linear_wgrad(dqkv, a, gw_all, acc, side.ws, bias=(gb_all, acc)), dqkv, a)
+            if lin.weight.requires_grad and lin.bias.requires_grad and os.environ.get("THEIA_WGRAD_GROUP", "auto") != "0":
+                probs.append((dy2, x2, gw2, accw2, (gb2, accb2)))
+            else:
+                side.run(lambda dy2=dy2, x2=x2, gw2=gw2, accw2=accw2, gb2=gb2, accb2=accb2:
+                         ops.linear_wgrad(dy2, x2, gw2, accw2, side.ws, bias=(gb2, accb2)), dy2, x2)
+        if len(probs) > 1:
+            side.run(lambda: ops.linear_wgrad_group(probs, side.ws), *[t for pr in probs for t in pr[:2]])
+        else:
+            side.run(lambda: ops.linear_wgrad(dqkv, a, gw_all, acc, side.ws, bias=(gb_all, acc)), dqkv, a)
         return True
 
     # ================================================================== translator heads
