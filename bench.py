@@ -273,8 +273,10 @@ def selfcheck_dispatch(fwd_bwd, engine):
             if c < worst_t:
                 worst_t, worst_name = c, name
     rel = abs(la - lb) / abs(lb)
-    return {"ok": bool(rel < 2e-3 and worst > 0.99), "loss_rel_diff": float(f"{rel:.3e}"), "worst_bucket_cosine": round(worst, 6),
-            "worst_tensor_cosine": round(worst_t, 6), "worst_tensor": worst_name}
+    # a single wrong tensor inside a large bucket cannot hide behind the bucket cosine: every tensor of >= 4096 elements > 0.98 (the gate
+    # of the model-level tests at their small batches; 0.9938 measured at the benched batch), the failing tensor is named
+    return {"ok": bool(rel < 2e-3 and worst > 0.99 and worst_t > 0.98), "loss_rel_diff": float(f"{rel:.3e}"), "worst_bucket_cosine": round(worst, 6),
+            "worst_tensor_cosine": round(worst_t, 6), "worst_tensor": worst_name, "tensor_gate": 0.98}
 
 
 def selfcheck_gemm_ulp(batch, dev):
@@ -653,7 +655,7 @@ def _main(argv=None):
                     "flops_per_launch": round(fsum / len(dom)),
                     "achieved_isolated": round(iso_tf, 1), "frac_isolated": round(iso_tf * 1e12 / MFMA_BF16_PEAK, 4),
                     # context, not the judged fraction: the chip is power-limited under MFMA streams of random bf16 operands -- an MFMA-only
-                    # stream with no data movement reaches 1513 TFLOP/s at a 1.44 GHz shader clock (tools/experiments/w4_probe.hip,
+                    # stream with no data movement reaches 1513 TFLOP/s at a 1.44 GHz shader clock (tools/experiments/w4_probe_not_kept.patch,
                     # profiles/r05_one_wave_per_simd_kernel_not_kept.txt); `peak` stays the 2.5 PFLOP/s of the microarchitecture guide
                     "power_limited_peak_r05_constant": 1513.0, "frac_isolated_of_power_limited_peak": round(iso_tf / 1513.0, 4),
                     "arithmetic_intensity_flop_per_byte": round(intensity, 1),

@@ -200,6 +200,9 @@ int theia_wgrad_splits_taps(int M, int N, int kslots, int in_c);
  * qualify (not bf16, not plain matrices, n > 4): launch them one by one then. */
 int theia_gemm_wgrad_group(const theia_wgrad_args_t* probs, int n, int dtype, void* stream);
 int theia_wgrad_group_splits(int M, int tiles);
+/* output tiles (per tap) the ping-pong weight-gradient kernel cuts [N, in_c] into: 256 x 256, or 128 (n) x 384 (c) where that is less MFMA
+ * work (N = in_c = 384: 3 instead of 4 at 56 % use); 0 when that kernel does not take the shape */
+int theia_wgrad_tiles(int N, int in_c);
 
 /* out[n*sn + slot*ss + ci*sc] (+)= sum_s slab[s][n][slot*C + ci]   (f32; permutes into the PyTorch layout) */
 int theia_wgrad_reduce(const float* slabs, int splits, int N, int kslots, int C, float* out, int64_t sn,

@@ -147,7 +147,10 @@ def test_wgrad_row_mode_of_a_launch_is_host_logic():
     # partial c tiles (round 4): in_c = 384 (DeiT-small) / 192 (DeiT-tiny) run the ping-pong kernel too
     assert plan(b * 197, C, ops.rm_plain(192, 192, C), C) == 111 and plan(b * 197, 384, ops.rm_plain(384, 384, 384), 384) == 111
     assert plan(b * 256, 384, ops.plan_conv3x3(384, 16).fwd[0][0], 384, 9) == 112 and plan(b * 256, 192, ops.plan_conv3x3(192, 16).fwd[0][0], 192, 9) == 112
-    assert lib.theia_wgrad_splits_taps(b * 256, 384, 9, 384) == 256 // (2 * 9 * 2)  # 2 n tiles x 9 taps x 2 c tiles (the second half used)
+    # round 6: N = in_c = 384 is cut into 128 (n) x 384 (c) tiles -- 3 per tap, all of them full -- instead of 2 x 2 of 256 x 256
+    assert lib.theia_wgrad_tiles(384, 384) == 3 and lib.theia_wgrad_tiles(768, 768) == 9 and lib.theia_wgrad_tiles(1152, 384) == 9
+    assert lib.theia_wgrad_tiles(192, 192) == 1 and lib.theia_wgrad_tiles(32, 768) == 0
+    assert lib.theia_wgrad_splits_taps(b * 256, 384, 9, 384) == 256 // (3 * 9)
     assert lib.theia_wgrad_splits_taps(b * 197, 768, 1, 768) == lib.theia_wgrad_splits(b * 197, 768, 768)
     for p_, want in ((ops.plan_conv3x3(C, 16), 112), (ops.plan_convT3x3(C, 14, 1, 0, 0), 112), (ops.plan_conv3x3(C, 8), 112)):
         assert not p_.wgrad_swapped

@@ -465,3 +465,20 @@ def test_optimizer_checkpoint_is_validated_and_remapped_by_parameter_name():
     assert all(torch.equal(a, st["m"]) for a, st in zip(before, o2.flat_state)) and o2.step_count == 7
     o2.load_state_dict(sd)  # and the positional path
     assert all(torch.equal(a["m"], b["m"]) for a, b in zip(o.flat_state, o2.flat_state))
+    # equal bucket sizes but another parameter order inside a bucket (two equally sized tensors swapped in the stored layout): by name,
+    # not positionally -- the moments follow the names
+    bi, (i0, i1) = next((bi, (i, j)) for bi, bk in enumerate(sd["layout"]) for i in range(len(bk)) for j in range(i + 1, len(bk))
+                        if bk[i][2] == bk[j][2] and bk[i][2] >= 64)
+    sw = dict(sd)
+    lay = [list(bk) for bk in sd["layout"]]
+    (n0, off0, k0), (n1, off1, _k1) = lay[bi][i0], lay[bi][i1]
+    lay[bi][i0], lay[bi][i1] = (n1, off0, k0), (n0, off1, k0)
+    sw["layout"] = lay
+    o2.load_state_dict(sw)
+    assert torch.equal(o2.flat_state[bi]["m"][off0:off0 + k0], o.flat_state[bi]["m"][off1:off1 + k0])
+    assert torch.equal(o2.flat_state[bi]["m"][off1:off1 + k0], o.flat_state[bi]["m"][off0:off0 + k0])
+    # moments for a parameter this model does not have: refused
+    lay2 = [list(bk) for bk in sd["layout"]]
+    lay2[0] = lay2[0] + [("no.such.parameter", 0, 8)]
+    with pytest.raises(ValueError, match="lacks"):
+        o2.load_state_dict(dict(sd, layout=lay2))

@@ -83,6 +83,7 @@ _SIGNATURES = {
     "theia_gemm_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_int, C.c_void_p]),
     "theia_gemm_wgrad_group": (C.c_int, [C.POINTER(WgradArgs), C.c_int, C.c_int, C.c_void_p]),
     "theia_wgrad_group_splits": (C.c_int, [C.c_int, C.c_int]),
+    "theia_wgrad_tiles": (C.c_int, [C.c_int, C.c_int]),
     "theia_wgrad_fuses_bias": (C.c_int, [C.POINTER(WgradArgs), C.c_int]),
     "theia_wgrad_splits": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "theia_wgrad_splits_taps": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -597,6 +597,7 @@ static int launch_wgrad(const theia_wgrad_args_t* a, hipStream_t stream) {
 int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream);  // gemm_wgrad_pp.hip
 bool theia_gemm_wgrad_pp_supported(const theia_wgrad_args_t* a);
 int theia_gemm_wgrad_pp_mode(const theia_wgrad_args_t* a);
+int theia_wgrad_pp_tiles_shape(int N, int in_c);  // output tiles per tap: 256 x 256, or 128 (n) x 384 (c) where that is less work
 
 static bool wgrad_use_pp() {
     static int v = -1;
@@ -612,7 +613,7 @@ extern "C" int theia_wgrad_splits_taps(int M, int N, int kslots, int in_c) {
     if (wgrad_use_pp() && in_c % 64 == 0 && in_c >= 128 && N >= 128) {
         // ping-pong kernel: 256x256 output tiles (per tap; the last c tile of a tap may be partial), one workgroup per CU -> fill one
         // round of the CU budget as exactly as possible
-        const int tiles = cdiv_i(N, 256) * kslots * cdiv_i(in_c, 256);
+        const int tiles = theia_wgrad_pp_tiles_shape(N, in_c) * kslots;
         // THEIA_WGRAD_CUS: workgroups (= CUs) a weight-gradient launch may fill -- fewer splits, each longer, and the rest of the chip stays
         // free for whatever the main stream runs beside it (A/B switch of the round-5 overlap experiments; default: the whole budget)
         static int wg_cus = -1;
@@ -639,7 +640,11 @@ extern "C" int theia_wgrad_splits_taps(int M, int N, int kslots, int in_c) {
 }
 extern "C" int theia_wgrad_splits(int M, int N, int Ktot) { return theia_wgrad_splits_taps(M, N, 1, Ktot); }
 
-// M-splits of a GROUPED launch (theia_gemm_wgrad_group): `tiles` = sum over its problems of ceil(N / 256) * ceil(in_c / 256), all with M rows
+// output tiles of one tap of a weight gradient with N output columns and in_c input channels on the ping-pong kernel (0: it does not take it)
+extern "C" int theia_wgrad_tiles(int N, int in_c) {
+    return wgrad_use_pp() && in_c % 64 == 0 && in_c >= 128 && N >= 128 ? theia_wgrad_pp_tiles_shape(N, in_c) : 0;
+}
+// M-splits of a GROUPED launch (theia_gemm_wgrad_group): `tiles` = sum over its problems of theia_wgrad_tiles(N, in_c), all with M rows
 extern "C" int theia_wgrad_group_splits(int M, int tiles) {
     int s = theia_compute_cus() / (tiles > 0 ? tiles : 1);
     const int smax = cdiv_i(M, 32) / 8;

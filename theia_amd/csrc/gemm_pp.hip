@@ -114,7 +114,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(PP_NUM_SGPR))) 
     // mode: the schedule positions above become eight QUEUES, one per XCD (position r * grid + q belongs to the XCD whose contiguous
     // range of round r holds q: the same L2 locality as the static rounds), and a workgroup draws its next item from the queue of the XCD
     // it runs on with a SCALAR atomic (s_atomic_add ... glc on a per-launch counter; tracked by lgkmcnt, which every R segment waits to
-    // zero anyway; the counter lives in that XCD's L2 and only that XCD's workgroups touch it: tools/experiments/satomic_probe.hip --
+    // zero anyway; the counter lives in that XCD's L2 and only that XCD's workgroups touch it: tools/experiments/satomic_probe_not_kept.patch --
     // ~760 cycles per draw, every queue a permutation).  The draw for the next tile is issued by wave 0 six half-tiles before this tile
     // ends and read one half-tile later; the result reaches the other waves through an LDS word, in time for the operand stream to cross
     // into it.  Between issue and wait the returned value sits in s100, an SGPR the compiler cannot allocate (amdgpu_num_sgpr): as an

@@ -30,6 +30,18 @@ __device__ __forceinline__ uint4 wp_tr_frag(const char* __restrict__ part, int l
     return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 
+// The same for the 128 (n) x 384 (c) tile (NB = 8, round 6): a ring slot is four sub-parts [32 rows][256 B] -- 128 dY columns, then the three
+// 128-column thirds of the activation tile -- with the 32-byte block index XORed with (row & 7) inside each 256-byte row.
+__device__ __forceinline__ uint4 wp_tr_frag_v(const char* __restrict__ sub, int lb, int lane) {
+    const int q = lane & 15, g = lane >> 4;
+    const int row = g * 4 + (q >> 2);
+    const char* p = sub + row * 256 + ((lb ^ (row & 7)) * 32) + (q & 3) * 8;
+    const wp_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wp_s16x4*)(p));
+    const wp_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wp_s16x4*)(p + 16 * 256));
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+
 // FAST: constant-step row addressing (see below); the host picks the instantiation, so the hot loop carries one path only
 // SPLIT_ISSUE: where the LDS-DMA of half-step h+NSTAGE-1 is issued (A/B switch THEIA_WGRAD_ISSUE=m: both rows in the M segment)
 // NSTAGE: ring depth, 4 (128 KB of LDS) or 5 (all 160 KB: one more half-step of prefetch distance; THEIA_WGRAD_STAGES)
@@ -44,22 +56,45 @@ __device__ __forceinline__ uint4 wp_tr_frag(const char* __restrict__ part, int l
 //      repeats with that period: each staged row carries a bit mask built once and the loop tests one bit of it
 // Measured (profiles/r03_ab_wgrad_row_modes.txt): the ~35 VALU instructions per staged row of mode 0 sit in the R / M segments of every
 // half-step; mode 1 took 19 % off the ViT weight-gradient launches.
-// The body of one workgroup: (tile, split) number `hw_bid` of the `nblocks` of problem p.  hw_bid % 8 must be the XCD the hardware put the
-// workgroup on (a launch's own blockIdx.x, or an index into a block range that starts at a multiple of 8: the grouped launch below).
-template <bool FAST, bool SPLIT_ISSUE, int NSTAGE, int MODE>
-__device__ __forceinline__ void wgrad_pp_body(const theia_wgrad_args_t& p, const int plain_order, const int hw_bid, const int nblocks) {
+// NB: 32-byte column blocks of dY per tile.  16 = the 256 (n) x 256 (c) tile above.  8 (round 6) = a 128 (n) x 384 (c) tile for channel
+//   counts that are multiples of 128 but not of 256 -- DeiT-small: N = in_c = 384 is 2 x 2 tiles of 256 at 56 % use, but 3 x 1 of these at
+//   100 %; eight waves of 96 (c) x 64 (n), 24 MFMAs per wave and half-step instead of 32 for the same 32 KB of operands.  Staging: ONE row per
+//   thread (row 4 * wave + lane / 16), its dY piece and its three activation pieces (sub-parts of [32][256 B]: wp_tr_frag_v) -- half the
+//   row state of the 256 x 256 form, the same four LDS-DMA operations per thread and half-step, two in each segment.
+// hardware places block b on XCD b % 8.  The blocks [first, first + n) of a launch -> 0 .. n-1 such that each XCD's blocks get a contiguous
+// range (gt_xcd_remap for a range that does not start at a multiple of 8: a problem inside a grouped launch)
+__device__ __forceinline__ int wp_xcd_remap_range(int b, int first, int n) {
+    const int x = b & 7;
+    int start = 0;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        const int fy = first + ((y - first) & 7);                       // first block >= `first` on XCD y
+        const int cy = fy < first + n ? (first + n - 1 - fy) / 8 + 1 : 0;  // blocks of the range on XCD y
+        start += y < x ? cy : 0;
+    }
+    const int fx = first + ((x - first) & 7);
+    return start + (b - fx) / 8;
+}
+
+// The body of one workgroup: block `hw_bid` (its blockIdx.x: hw_bid % 8 is the XCD it runs on) of the blocks [first, first + nblocks) that
+// problem p owns in the launch (first = 0: a launch of its own).
+template <bool FAST, bool SPLIT_ISSUE, int NSTAGE, int MODE, int NB = 16>
+__device__ __forceinline__ void wgrad_pp_body(const theia_wgrad_args_t& p, const int plain_order, const int hw_bid, const int nblocks, const int first = 0) {
     constexpr bool wgrad_split_issue = SPLIT_ISSUE;
-    constexpr int MS = 32, ROWB = 512, PART = MS * ROWB, STAGE = 2 * PART;
+    constexpr bool V = NB == 8;  // the 128 x 384 tile
+    static_assert(NB == 16 || (NB == 8 && FAST && SPLIT_ISSUE), "the 128 x 384 tile: stepping instantiations with the split issue only");
+    constexpr int TN = V ? 128 : 256, TC = V ? 384 : 256, WC = V ? 96 : 128;  // tile columns (n, c), c columns per wave
+    constexpr int MS = 32, ROWB = 512, PART = MS * ROWB, STAGE = 2 * PART, SUB = MS * 256;
     constexpr int AHEAD = NSTAGE - 1;  // half-steps in flight ahead of the one being multiplied; 4 LDS-DMA operations per thread each
-    constexpr int FM = 8, FN = 4;
+    constexpr int FM = V ? 6 : 8, FN = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const int ugroup = uwave >> 2;
-    const int wm = wave >> 2, wn = wave & 3;   // wm: which 128 c-columns (= wave group), wn: which 64 n-columns
+    const int wm = V ? wave >> 1 : wave >> 2, wn = V ? wave & 1 : wave & 3;   // wm: which WC c-columns, wn: which 64 n-columns
     const theia_rowmap_t& mp = p.map;
-    const int tiles_n = (p.N + 255) / 256;
-    const int tiles_c = (mp.in_c + 255) / 256;  // (the last c tile may be partial: in_c = 384, 192 -- columns past in_c read zeros and are not stored)
+    const int tiles_n = (p.N + TN - 1) / TN;
+    const int tiles_c = (mp.in_c + TC - 1) / TC;  // (the last c tile may be partial: in_c = 384, 192 -- columns past in_c read zeros and are not stored)
     const int ntile = tiles_n * mp.ntaps * tiles_c;
     // hardware places block b on XCD b % 8: give each XCD a contiguous range of (split, tile) so that the workgroups sharing a dY
     // column tile or an activation (tap, c) tile meet in one L2 (THEIA_WGRAD_XCD=0: A/B switch, plain order)
@@ -68,11 +103,11 @@ __device__ __forceinline__ void wgrad_pp_body(const theia_wgrad_args_t& p, const
     // c tile's slice of the gathered operand enters the L2 once instead of once per tap, beside the split's dense rows.  With the tap
     // slowest (rounds 2-5; plain_order & 2: A/B switch THEIA_WGRAD_XCD=tap) an XCD held ~3 taps x every c tile: the stride-2 launches fetched
     // 2.8 GB for ~1 GB of operands at 3.4 TB/s (profiles/r05_bench_pmc_traffic.json).
-    const int bid = (plain_order & 1) ? hw_bid : gt_xcd_remap(hw_bid, nblocks);
+    const int bid = (plain_order & 1) ? hw_bid - first : first == 0 ? gt_xcd_remap(hw_bid, nblocks) : wp_xcd_remap_range(hw_bid, first, nblocks);
     const int tile = bid % ntile, split = bid / ntile;
     const int tn = tile % tiles_n, tk = tile / tiles_n;
     const int tap = (plain_order & 2) ? tk / tiles_c : tk % mp.ntaps;
-    const int c0 = ((plain_order & 2) ? tk - tap * tiles_c : tk / mp.ntaps) * 256, n0 = tn * 256;
+    const int c0 = ((plain_order & 2) ? tk - tap * tiles_c : tk / mp.ntaps) * TC, n0 = tn * TN;
     const int dy = mp.dy[tap], dx = mp.dx[tap];
 
     const int nsteps = (p.M + MS - 1) / MS;
@@ -87,17 +122,19 @@ __device__ __forceinline__ void wgrad_pp_body(const theia_wgrad_args_t& p, const
     const uint64_t zp = reinterpret_cast<uint64_t>(g_wp_zero_page);
 
     // ---- this thread's staging column (fixed) and its two rows' decode state
-    const int srow = tid >> 5, s16 = tid & 31;
+    // (128 x 384 tile: ONE row per thread, 4 * wave + lane / 16, and a 16-byte piece of each of the four 128-column sub-parts)
+    const int srow = V ? uwave * 4 + (lane >> 4) : tid >> 5, s16 = V ? lane & 15 : tid & 31;
     const int pb = s16 >> 1;
-    const int lb = (pb & 8) | ((pb & 7) ^ (srow & 7));
-    const int col = (lb * 2 + (s16 & 1)) * 8;            // element column inside the 256-wide tile
+    const int lb = V ? pb ^ (srow & 7) : (pb & 8) | ((pb & 7) ^ (srow & 7));
+    const int col = (lb * 2 + (s16 & 1)) * 8;            // element column inside the 256-wide tile (the 128-wide sub-part)
     const bool n_ok = n0 + col < p.N;
     const bool c_ok = c0 + col < mp.in_c;
+    const bool c_ok1 = c0 + 128 + col < mp.in_c, c_ok2 = c0 + 256 + col < mp.in_c;  // (V: the second and third activation sub-parts)
     const float rcpW = 1.0f / (float)mp.rows_w, rcpH = 1.0f / (float)mp.rows_h;
     int st_m[2], st_img[2], st_ry[2], st_rx[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int m = s_begin * MS + srow + 16 * i;
+        const int m = s_begin * MS + srow + (V ? 0 : 16 * i);
         const int R = mp.rows_h * mp.rows_w;
         st_m[i] = m;
         st_img[i] = m / R;
@@ -138,7 +175,7 @@ __device__ __forceinline__ void wgrad_pp_body(const theia_wgrad_args_t& p, const
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             for (int k = 0; k < period; ++k) {
-                const int rem = srow + 16 * i + MS * k;
+                const int rem = srow + (V ? 0 : 16 * i) + MS * k;
                 const int ry = rem / mp.rows_w, rx = rem - ry * mp.rows_w;
                 const bool ok = ((unsigned)(ry - ry_lo) < ry_span) & ((unsigned)(rx - rx_lo) < rx_span);
                 vmask[i] |= (ok ? 1u : 0u) << k;
@@ -157,6 +194,50 @@ __device__ __forceinline__ void wgrad_pp_body(const theia_wgrad_args_t& p, const
     }
     // issue the dY piece and the activation piece of row i for the current half-step, then advance the row by 32
     auto issue_row = [&](int i, char* slot) {
+        if constexpr (V) {
+            // half 0 (R segment): the dY piece and the first activation piece; half 1 (M segment): the other two, then the row moves on
+            const bool mok = st_m[0] < m_limit;
+            bool xok = mok;
+            if constexpr (MODE == 2) xok = mok & (((vmask[0] >> phase[0]) & 1u) != 0u);
+            else if constexpr (MODE == 0) xok = mok & ((unsigned)(st_ry[0] - ry_lo) < ry_span) & ((unsigned)(st_rx[0] - rx_lo) < rx_span);
+            char* dst = slot + uwave * (4 * 256);
+            if (i == 0) {
+                const uint64_t sy = (mok & n_ok) ? f_py[0] : zp;
+                const uint64_t sx = (xok & c_ok) ? f_px[0] : zp;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sy, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx, (__attribute__((address_space(3))) void*)(dst + SUB), 16, 0, 0);
+                return;
+            }
+            const uint64_t s1 = (xok & c_ok1) ? f_px[0] + 256 : zp;
+            const uint64_t s2 = (xok & c_ok2) ? f_px[0] + 512 : zp;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s1, (__attribute__((address_space(3))) void*)(dst + 2 * SUB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s2, (__attribute__((address_space(3))) void*)(dst + 3 * SUB), 16, 0, 0);
+            i = 0;  // ... and advance row 0 through the common code below
+            st_m[0] += MS;
+            if constexpr (MODE == 1) {
+                f_py[0] += (uint64_t)(int64_t)by_step;
+                f_px[0] += (uint64_t)(int64_t)bx_step;
+                return;
+            }
+            if constexpr (MODE == 2) {
+                const bool wrap = phase[0] + 1 == period;
+                f_py[0] += (uint64_t)(int64_t)(wrap ? by_step + by_wy : by_step);
+                f_px[0] += (uint64_t)(int64_t)(wrap ? bx_step + bx_wy : bx_step);
+                phase[0] = wrap ? 0 : phase[0] + 1;
+                return;
+            }
+            int rx = st_rx[0] + r32;
+            const bool wx = rx >= mp.rows_w;
+            rx = wx ? rx - mp.rows_w : rx;
+            int ry = st_ry[0] + q32 + (wx ? 1 : 0);
+            const bool wy = ry >= mp.rows_h;
+            ry = wy ? ry - mp.rows_h : ry;
+            st_rx[0] = rx;
+            st_ry[0] = ry;
+            f_py[0] += (uint64_t)(int64_t)(by_step + (wx ? by_wx : 0) + (wy ? by_wy : 0));
+            f_px[0] += (uint64_t)(int64_t)(bx_step + (wx ? bx_wx : 0) + (wy ? bx_wy : 0));
+            return;
+        }
         const bool mok = st_m[i] < m_limit;
         uint64_t sy, sx;
         if constexpr (MODE == 1) {
@@ -264,9 +345,12 @@ __device__ __forceinline__ void wgrad_pp_body(const theia_wgrad_args_t& p, const
             // ---------------- R(h): 12 transposed fragments (24 ds_read_b64_tr_b16)
             uint4 fa[FM];
 #pragma unroll
-            for (int i = 0; i < FN; ++i) fb[i] = wp_tr_frag(sy, wn * 4 + i, lane);
+            for (int i = 0; i < FN; ++i) fb[i] = V ? wp_tr_frag_v(sy, wn * 4 + i, lane) : wp_tr_frag(sy, wn * 4 + i, lane);
 #pragma unroll
-            for (int j = 0; j < FM; ++j) fa[j] = wp_tr_frag(sx, wm * 8 + j, lane);
+            for (int j = 0; j < FM; ++j) {
+                if constexpr (V) fa[j] = wp_tr_frag_v(sy + SUB * (1 + ((wm * 6 + j) >> 3)), (wm * 6 + j) & 7, lane);  // c block wm * 6 + j of 24
+                else fa[j] = wp_tr_frag(sx, wm * 8 + j, lane);
+            }
             // Row 0 of half-step h+AHEAD is issued here, row 1 between the MFMAs below: an issue_row is 2 LDS-DMA instructions (~100
             // issue cycles each) + ~40 VALU.  With both in the M segment it was ~1200 cycles against ~600 for R -- the matrix pipe 40 %
             // busy (PMC) -- since the other group's R segment cannot run longer than this group's M; one in each balances them.
@@ -318,17 +402,17 @@ __device__ __forceinline__ void wgrad_pp_body(const theia_wgrad_args_t& p, const
     for (int i = 0; i < FN; ++i) {
         const int n = n0 + wn * 64 + i * 16 + q;
         if (n >= p.N) continue;
-        float* drow = slab + (int64_t)n * krow + (int64_t)mp.wslot[tap] * mp.in_c + c0 + wm * 128 + g * 4;
-        const int c_left = mp.in_c - (c0 + wm * 128 + g * 4);  // columns of this lane's first float4 up to the end of the tap's c range
+        float* drow = slab + (int64_t)n * krow + (int64_t)mp.wslot[tap] * mp.in_c + c0 + wm * WC + g * 4;
+        const int c_left = mp.in_c - (c0 + wm * WC + g * 4);  // columns of this lane's first float4 up to the end of the tap's c range
 #pragma unroll
         for (int j = 0; j < FM; ++j)
             if (j * 16 < c_left) *reinterpret_cast<float4*>(drow + j * 16) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     }
 }
 
-template <bool FAST, bool SPLIT_ISSUE = true, int NSTAGE = 4, int MODE = 0>
+template <bool FAST, bool SPLIT_ISSUE = true, int NSTAGE = 4, int MODE = 0, int NB = 16>
 __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_args_t p, const int plain_order) {
-    wgrad_pp_body<FAST, SPLIT_ISSUE, NSTAGE, MODE>(p, plain_order, (int)blockIdx.x, (int)gridDim.x);
+    wgrad_pp_body<FAST, SPLIT_ISSUE, NSTAGE, MODE, NB>(p, plain_order, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Grouped launch (round 6): up to WGRAD_GROUP_MAX plain-matrix problems (mode 1: the nn.Linear weight gradients) in ONE grid.  Why: a
@@ -336,23 +420,22 @@ __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_ar
 // (o_proj), each split 900 rows long: 28 prologues, 28 f32 partials of every tile to write and to reduce again (66 MB for a 2.4 MB
 // result), 713 TFLOP/s against 1.0-1.07 PFLOP/s for the 27 / 36-tile gradients.  o_proj's and the fused q/k/v gradient of a layer share M
 // and are both at hand when the attention backward has run: together they are 36 tiles x 7 splits of 3602 rows -- the same shape of
-// launch as fc1's and fc2's.  Block ranges start at multiples of 8 (the XCD of a workgroup is blockIdx.x % 8 whatever the problem).
+// launch as fc1's and fc2's.  The problems' block ranges follow each other without gaps (wp_xcd_remap_range keeps each XCD's blocks of a
+// problem on contiguous tiles wherever the range starts): 36 tiles x 7 splits are 252 workgroups, not 260.
 constexpr int WGRAD_GROUP_MAX = 4;
 struct wgrad_group_t {
     int nprob;
-    int first[WGRAD_GROUP_MAX];   // first block of problem k (a multiple of 8)
+    int first[WGRAD_GROUP_MAX];   // first block of problem k
     int count[WGRAD_GROUP_MAX];   // its tiles x splits
     theia_wgrad_args_t prob[WGRAD_GROUP_MAX];
 };
-template <int NSTAGE>
+template <int NSTAGE, int NB = 16>
 __global__ __launch_bounds__(512) void gemm_wgrad_pp_group_kernel(const wgrad_group_t g, const int plain_order) {
     int k = 0;
 #pragma unroll
     for (int i = 1; i < WGRAD_GROUP_MAX; ++i)
         if (i < g.nprob && (int)blockIdx.x >= g.first[i]) k = i;
-    const int local = (int)blockIdx.x - g.first[k];
-    if (local >= g.count[k]) return;  // (padding up to the next multiple of 8)
-    wgrad_pp_body<true, true, NSTAGE, 1>(g.prob[k], plain_order, local, g.count[k]);
+    wgrad_pp_body<true, true, NSTAGE, 1, NB>(g.prob[k], plain_order, (int)blockIdx.x, g.count[k], g.first[k]);
 }
 
 // out[n] (+)= sum_s part[s*N + n], fixed order
@@ -367,6 +450,33 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
 
 // in_c a multiple of 64 (the last of ceil(in_c / 256) c tiles may be partial: DeiT-small's 384, DeiT-tiny's 192), at least half a tile of n
 bool theia_gemm_wgrad_pp_supported(const theia_wgrad_args_t* a) { return a->map.in_c % 64 == 0 && a->map.in_c >= 128 && a->N >= 128; }
+
+// Tile of a launch: 256 (n) x 256 (c), or 128 x 384 (returns 8: NB of the kernel) when that is less MFMA work -- tiles x 0.75 against tiles
+// (N = in_c = 384: 3 x 0.75 against 4; N = 1152, in_c = 384: 9 x 0.75 against 10; multiples of 256 tie and stay).  THEIA_WGRAD_TILE=256 |
+// 384: A/B switch (384 where the kernel can: stepping row modes, split issue, 4-deep ring).
+int theia_gemm_wgrad_pp_mode(const theia_wgrad_args_t* a);
+int theia_wgrad_pp_nb_shape(int N, int in_c) {
+    static int force = -1;
+    if (force < 0) {
+        const char* e = getenv("THEIA_WGRAD_TILE");
+        force = e == nullptr ? 0 : atoi(e);
+        const char* e2 = getenv("THEIA_WGRAD_ISSUE");
+        const char* e3 = getenv("THEIA_WGRAD_STAGES");
+        if ((e2 != nullptr && strcmp(e2, "m") == 0) || (e3 != nullptr && atoi(e3) == 5)) force = 256;  // those A/B switches exist for the 256 x 256 tile only
+    }
+    if (force == 256) return 16;
+    const long t256 = (long)cdiv_i(N, 256) * cdiv_i(in_c, 256) * 4, t384 = (long)cdiv_i(N, 128) * cdiv_i(in_c, 384) * 3;
+    return force == 384 || t384 < t256 ? 8 : 16;
+}
+int theia_wgrad_pp_nb(const theia_wgrad_args_t* a) {
+    const int mode = theia_gemm_wgrad_pp_mode(a);
+    if (mode < 10) return 16;  // the per-row decode path (maps the stepping cannot take) has the 256 x 256 tile only
+    return theia_wgrad_pp_nb_shape(a->N, a->map.in_c);
+}
+// output tiles of a launch per tap
+int theia_wgrad_pp_tiles_shape(int N, int in_c) {
+    return theia_wgrad_pp_nb_shape(N, in_c) == 8 ? cdiv_i(N, 128) * cdiv_i(in_c, 384) : cdiv_i(N, 256) * cdiv_i(in_c, 256);
+}
 
 // Which row addressing the launch will use (host logic only; exported through theia_gemm_wgrad_plan): 0 = per-row decode (the maps
 // the stepping path cannot take), 10 = stepping (mode 0), 11 = plain matrices (mode 1), 12 = periodic (mode 2).  -1: not this kernel.
@@ -421,15 +531,17 @@ int theia_gemm_wgrad_pp_group_launch(const theia_wgrad_args_t* a, int n, hipStre
         g.count[k] = 0;
         if (k >= n) continue;
         if (theia_gemm_wgrad_pp_mode(&a[k]) != 11) return THEIA_ERR_UNSUPPORTED;
+        if (theia_wgrad_pp_nb(&a[k]) != theia_wgrad_pp_nb(&a[0])) return THEIA_ERR_UNSUPPORTED;  // one tile form per launch
         g.prob[k] = a[k];
-        g.count[k] = cdiv_i(a[k].N, 256) * cdiv_i(a[k].map.in_c, 256) * a[k].splits;
-        next = (next + g.count[k] + 7) & ~7;
+        g.count[k] = theia_wgrad_pp_tiles_shape(a[k].N, a[k].map.in_c) * a[k].splits;
+        next += g.count[k];
     }
     constexpr int lds4 = 4 * 2 * 32 * 512, lds5 = 5 * 2 * 32 * 512;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_group_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_group_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds5);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_wgrad_pp_group_kernel<4, 8>)), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
         attr_set = true;
     }
     static int stages = -1;
@@ -438,7 +550,8 @@ int theia_gemm_wgrad_pp_group_launch(const theia_wgrad_args_t* a, int n, hipStre
         stages = e != nullptr && atoi(e) == 5 ? 5 : 4;
     }
     const dim3 grid(g.first[n - 1] + g.count[n - 1]);
-    if (stages == 5) hipLaunchKernelGGL(gemm_wgrad_pp_group_kernel<5>, grid, dim3(512), lds5, stream, g, wgrad_plain_order());
+    if (theia_wgrad_pp_nb(&a[0]) == 8) hipLaunchKernelGGL((gemm_wgrad_pp_group_kernel<4, 8>), grid, dim3(512), lds4, stream, g, wgrad_plain_order());
+    else if (stages == 5) hipLaunchKernelGGL(gemm_wgrad_pp_group_kernel<5>, grid, dim3(512), lds5, stream, g, wgrad_plain_order());
     else hipLaunchKernelGGL(gemm_wgrad_pp_group_kernel<4>, grid, dim3(512), lds4, stream, g, wgrad_plain_order());
     THEIA_CHECK_LAUNCH("theia_gemm_wgrad_group(pp)");
     for (int k = 0; k < n; ++k)
@@ -463,6 +576,9 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true, true, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true, true, 5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds5);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true, true, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_wgrad_pp_kernel<true, true, 4, 0, 8>)), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_wgrad_pp_kernel<true, true, 4, 1, 8>)), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_wgrad_pp_kernel<true, true, 4, 2, 8>)), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
         attr_set = true;
     }
     static int stages = -1;  // THEIA_WGRAD_STAGES=4|5: ring depth of the stepping instantiation
@@ -470,7 +586,8 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
         const char* e = getenv("THEIA_WGRAD_STAGES");
         stages = e != nullptr && atoi(e) == 5 ? 5 : 4;
     }
-    const int tiles = cdiv_i(a->N, 256) * a->map.ntaps * cdiv_i(a->map.in_c, 256);
+    const int nb = theia_wgrad_pp_nb(a);
+    const int tiles = (nb == 8 ? cdiv_i(a->N, 128) * cdiv_i(a->map.in_c, 384) : cdiv_i(a->N, 256) * cdiv_i(a->map.in_c, 256)) * a->map.ntaps;
     static int issue_in_m = -1;
     if (issue_in_m < 0) {
         const char* e = getenv("THEIA_WGRAD_ISSUE");
@@ -479,7 +596,10 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
     const int plain_order = wgrad_plain_order();
     const int mode = theia_gemm_wgrad_pp_mode(a);
     const dim3 grid(tiles * a->splits);
-    if (mode == 11 && stages == 5) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 5, 1>), grid, dim3(512), lds5, stream, *a, plain_order);
+    if (nb == 8 && mode == 11) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 1, 8>), grid, dim3(512), lds4, stream, *a, plain_order);
+    else if (nb == 8 && mode == 12) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 2, 8>), grid, dim3(512), lds4, stream, *a, plain_order);
+    else if (nb == 8) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 0, 8>), grid, dim3(512), lds4, stream, *a, plain_order);
+    else if (mode == 11 && stages == 5) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 5, 1>), grid, dim3(512), lds5, stream, *a, plain_order);
     else if (mode == 11) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 1>), grid, dim3(512), lds4, stream, *a, plain_order);
     else if (mode == 12) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 2>), grid, dim3(512), lds4, stream, *a, plain_order);
     else if (mode == 10 && issue_in_m) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, false>), grid, dim3(512), lds4, stream, *a, plain_order);

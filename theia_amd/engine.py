@@ -646,14 +646,14 @@ class StudentEngine:
         dz = dz.contiguous().view(M, D)
         if dz.dtype != T:
             raise TypeError(f"gradient dtype {dz.dtype} does not match the engine's compute dtype {T}")
+        _wt = lambda n_, k_: max(1, N.lib().theia_wgrad_tiles(n_, k_))  # output tiles of a weight gradient (256 x 256 or 128 x 384)
         wsz = max(N.lib().theia_layernorm_bwd_workspace_bytes(M, D) // 4, N.lib().theia_colsum_workspace_bytes(M, F) // 4,
                   N.lib().theia_colsum_workspace_bytes(b, NTOK * D) // 4,
                   max(ops.wgrad_splits(M, n_, k_) * n_ * (k_ + 1) for n_, k_ in ((D, F), (F, D), (D, D), (3 * D, D), (D, 768))),  # slabs + bias partials
                   # the grouped q/k/v + o_proj launch: one split count for both problems
-                  N.lib().theia_wgrad_group_splits(M, (-(-3 * D // 256) + -(-D // 256)) * -(-D // 256)) * 4 * D * (D + 1),
+                  N.lib().theia_wgrad_group_splits(M, _wt(3 * D, D) + _wt(D, D)) * 4 * D * (D + 1),
                   # ... and with fc1 / fc2 in it (the small students)
-                  N.lib().theia_wgrad_group_splits(M, (-(-3 * D // 256) + -(-D // 256)) * -(-D // 256) + 2 * -(-F // 256) * -(-D // 256))
-                  * (4 * D * (D + 1) + F * (D + 1) + D * (F + 1)))
+                  N.lib().theia_wgrad_group_splits(M, _wt(3 * D, D) + _wt(D, D) + _wt(F, D) + _wt(D, F)) * (4 * D * (D + 1) + F * (D + 1) + D * (F + 1)))
         ws = self.ws(wsz, dev)
         side = self._side_queue(dev, wsz)
 
@@ -671,7 +671,7 @@ class StudentEngine:
         # launch; when ALL FOUR weight gradients of a layer are few tiles (DeiT-small: 38, DeiT-tiny: 10 -- a launch of their own each
         # would be 4-64 M-splits of a handful of tiles, 30-70 us apiece), fc2's and fc1's wait as well: one launch per layer.  DeiT-base
         # (108 tiles = 2 splits on 216 of 256 CUs) keeps fc1 / fc2 on their own 36 x 7 launches.  THEIA_WGRAD_GROUP=0 / 1 / all: A/B.
-        tl = lambda n_, k_: -(-n_ // 256) * -(-k_ // 256)
+        tl = lambda n_, k_: max(1, N.lib().theia_wgrad_tiles(n_, k_))
         gmode = os.environ.get("THEIA_WGRAD_GROUP", "auto")
         group_all = T == torch.bfloat16 and (gmode == "all" or (gmode == "auto" and tl(3 * D, D) + tl(D, D) + tl(F, D) + tl(D, F) <= 64))
         pending: List[Tuple[torch.Tensor, torch.Tensor, Any]] = []

@@ -372,8 +372,8 @@ def linear_wgrad_group(problems, ws: Optional[torch.Tensor] = None) -> None:
     ok = _dt(problems[0][0]) == N.BF16 and len(problems) <= 4 and all(dy.shape[0] == M and dy.dtype == problems[0][0].dtype
                                                                       for dy, *_ in problems)
     if ok:
-        tiles = sum(-(-dy.shape[1] // 256) * -(-x.shape[1] // 256) for dy, x, *_ in problems)
-        splits = N.lib().theia_wgrad_group_splits(M, tiles)
+        tiles = sum(N.lib().theia_wgrad_tiles(dy.shape[1], x.shape[1]) for dy, x, *_ in problems)
+        splits = N.lib().theia_wgrad_group_splits(M, max(1, tiles))
         need = sum(splits * dy.shape[1] * (x.shape[1] + 1) for dy, x, *_ in problems)
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.float32, device=problems[0][0].device)

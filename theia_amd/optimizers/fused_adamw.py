@@ -187,8 +187,12 @@ class FusedAdamW(torch.optim.Optimizer):
         if len(ms) != len(vs):
             raise ValueError("FusedAdamW.load_state_dict: 'm' and 'v' lists differ in length")
         plan = None
-        if [int(m.numel()) for m in ms] != mine:
-            lay = sd.get("layout")
+        lay = sd.get("layout")
+        # positional load only when the layouts are known to agree: equal per-bucket sizes with another parameter order or other offsets
+        # inside a bucket would attach the moments to the wrong parameters (a checkpoint without a layout -- rounds 1-3 -- can only be
+        # checked by size)
+        same = [int(m.numel()) for m in ms] == mine and (lay is None or [[tuple(e) for e in bk] for bk in lay] == self._layout())
+        if not same:
             if lay is None:
                 raise ValueError(f"FusedAdamW.load_state_dict: checkpoint buckets {[int(m.numel()) for m in ms]} do not match this model's "
                                  f"{mine} and the checkpoint carries no layout to re-map by parameter name")
@@ -199,6 +203,11 @@ class FusedAdamW(torch.optim.Optimizer):
                     if name not in src or src[name][2] != n or src[name][1] + n > int(ms[src[name][0]].numel()):
                         raise ValueError(f"FusedAdamW.load_state_dict: parameter {name!r} ({n} elements) is not in the checkpoint's layout")
                     plan.append((bi, off, src[name][0], src[name][1], n))
+            have = {name for bucket in self._layout() for name, _o, _n in bucket}
+            extra = sorted(set(src) - have)
+            if extra:  # moments of parameters this model does not have: refuse rather than drop them silently
+                raise ValueError(f"FusedAdamW.load_state_dict: the checkpoint holds moments for parameters this model lacks: {extra[:5]}"
+                                 f"{' ...' if len(extra) > 5 else ''}")
         self.step_count = int(sd["step_count"])
         for g, sg in zip(self.param_groups, sd["param_groups"]):
             g.update(sg)

@@ -315,6 +315,7 @@ class TheiaDataParallel(torch.nn.Module):
         self.dynamic_schedule = False            # set by autotune_reserved_cus when the work-conserving tile schedule wins on this job
         self.autotune_dynamic_ms: Optional[float] = None
         self._saved_cus: Optional[int] = None  # the budget in force before this wrapper shrank it (None: not shrunk)
+        self._saved_sched: Optional[bool] = None  # the tile schedule in force before a backward window switched the dynamic one on
         if self.reducer.world > 1:
             module.engine.bucket_ready_hook = self._on_bucket
             first = next(iter(module.parameters()), None)
@@ -337,7 +338,7 @@ class TheiaDataParallel(torch.nn.Module):
             ops.set_compute_cus(self._saved_cus)
             self._saved_cus = None
 
-    def autotune_reserved_cus(self, step_fn: Callable[[], object], candidates=(0, 16, 32, 64), steps: int = 3,
+    def autotune_reserved_cus(self, step_fn: Callable[[], object], candidates=(0, 16, 32, 64), steps: int = 5,
                               min_gain: float = 0.01, try_dynamic: bool = True) -> dict:
         """Measure, at start-up, how many CUs the GEMM planners should leave to RCCL while gradient buckets are in flight, and keep the
         best: ``step_fn()`` (one whole training step) is timed ``steps`` times per candidate (max over ranks), ``pick_reservation``
@@ -375,7 +376,7 @@ class TheiaDataParallel(torch.nn.Module):
         if try_dynamic and hasattr(ops, "set_gemm_schedule"):
             keep = self._reserve
             self._reserve = 0
-            prev = ops.set_gemm_schedule(True)
+            self.dynamic_schedule = True  # (scoped to the backward window like the CU budget: _on_bucket switches it on, _finalize off)
             try:
                 step_fn()
                 torch.cuda.synchronize(dev)
@@ -387,14 +388,23 @@ class TheiaDataParallel(torch.nn.Module):
                 tt = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.reducer.pg)
                 self.autotune_dynamic_ms = float(tt.item())
-            finally:
-                ops.set_gemm_schedule(prev)
-            if self.autotune_dynamic_ms < results[keep] * (1.0 - min_gain):
-                self.dynamic_schedule = True
-                ops.set_gemm_schedule(True)  # (every rank reaches the same decision: the timings are reduced with MAX)
-            else:
+            except BaseException:
+                self.dynamic_schedule = False
+                self._reserve = keep  # the arrangement pick_reservation chose stays in force
+                self._restore_sched()
+                raise
+            # it has to beat the best static arrangement by TWICE the margin a reservation needs: the decision rests on a handful of steps,
+            # and a wrong "on" costs every backward pass the schedule's 3-8 % (every rank reaches the same decision: MAX-reduced timings)
+            if not self.autotune_dynamic_ms < results[keep] * (1.0 - 2.0 * min_gain):
+                self.dynamic_schedule = False
                 self._reserve = keep
         return results
+
+    def _restore_sched(self) -> None:
+        from . import ops
+        if self._saved_sched is not None:
+            ops.set_gemm_schedule(self._saved_sched)
+            self._saved_sched = None
 
     def _on_bucket(self, bucket, side_event=None) -> None:
         if not self._callback_queued:
@@ -403,6 +413,9 @@ class TheiaDataParallel(torch.nn.Module):
             self._callback_queued = True
             if self._reserve:
                 self._shrink_cus()  # launches enqueued from here on leave these CUs to the collectives
+            if self.dynamic_schedule and self._saved_sched is None:
+                from . import ops
+                self._saved_sched = ops.set_gemm_schedule(True)  # ... or draw their tiles from the per-XCD queues; forward / eval launches never do
         self.reducer.bucket_ready(bucket.flat, side_event)
 
     def _finalize(self) -> None:
@@ -410,11 +423,13 @@ class TheiaDataParallel(torch.nn.Module):
             self.reducer.finish()
         finally:
             self._restore_cus()
+            self._restore_sched()
             self._callback_queued = False
 
     def forward(self, *args, **kwargs):
         # a backward pass that raised never reached _finalize: do not run the next step on the reduced budget / with stale state
         self._restore_cus()
+        self._restore_sched()
         if self._callback_queued:
             self._callback_queued = False
             self.reducer._pending.clear()

@@ -7,10 +7,10 @@
 #include <vector>
 #include <string>
 #include "../theia_amd/csrc/gemm_pp.hip"
-#ifdef WITH_W4  // the one-wave-per-SIMD experiment (tools/experiments/gemm_w4.hip, tile 256004): not kept, not in the library
+#ifdef WITH_W4  // the one-wave-per-SIMD experiment (tools/experiments/gemm_w4_not_kept.patch: git apply it first; tile 256004): not kept, not in the library
 #include "experiments/gemm_w4.hip"
 #endif
-#ifdef WITH_DW  // the dual-workgroup experiment (tools/experiments/gemm_dw.hip): not kept, not in the library
+#ifdef WITH_DW  // the dual-workgroup experiment (tools/experiments/gemm_dw_not_kept.patch: git apply it first): not kept, not in the library
 #include "experiments/gemm_dw.hip"
 #endif
 
