@@ -142,7 +142,9 @@ def test_wgrad_row_mode_of_a_launch_is_host_logic():
 
     assert plan(b * 197, C, ops.rm_plain(C, C, C), C) == 111 and plan(b * 197, 3 * C, ops.rm_plain(C, C, 3 * C), 3 * C) == 111
     assert plan(b * 197, C, ops.rm_plain(C, C, C), C, dtype=N.F32) == 0          # exact-f32 mode: the 2-stage kernel
-    assert plan(b * 4096, 32, ops.rm_plain(C, C, 32), 32) == 0                   # N < 128
+    assert plan(b * 256, 32, ops.rm_plain(C, C, 32), 32) == 0                    # N < 128
+    assert plan(b * 4096, 32, ops.rm_plain(C, C, 32), 32) == 111                 # ... unless M is huge (round 6: the Depth head, read-bound)
+    assert lib.theia_wgrad_splits(b * 4096, 32, C) == 128                        # 2 tiles of 128 (n) x 384 (c): a split per CU
     assert plan(b * 197, C, ops.rm_plain(96, 96, C), C) == 0                     # in_c < 128
     # partial c tiles (round 4): in_c = 384 (DeiT-small) / 192 (DeiT-tiny) run the ping-pong kernel too
     assert plan(b * 197, C, ops.rm_plain(192, 192, C), C) == 111 and plan(b * 197, 384, ops.rm_plain(384, 384, 384), 384) == 111

@@ -178,7 +178,8 @@ def test_linear_bias_epilogues(dt, M, N, K, tile):
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(197 * 4, 192, 192), (1000, 128, 256), (4096 + 37, 64, 64), (513, 1280, 192), (300, 32, 384), (2049, 24, 128), (777, 8, 64),
                                    (197 * 9, 768, 768), (2000, 3072, 768), (5000, 256, 768), (96, 1280, 768),
-                                   (1500, 384, 384), (777, 1536, 384), (900, 384, 1536), (600, 576, 192), (1111, 192, 768), (650, 1024, 320)])
+                                   (1500, 384, 384), (777, 1536, 384), (900, 384, 1536), (600, 576, 192), (1111, 192, 768), (650, 1024, 320),
+                                   (262144 + 96, 32, 384)])  # skinny output over very many rows (the Depth head at b = 64: ping-pong kernel, 256 splits)
 def test_linear_wgrad_and_colsum(dt, M, N, K):
     from theia_amd import ops
     dev = _dev()

@@ -598,6 +598,7 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream);
 bool theia_gemm_wgrad_pp_supported(const theia_wgrad_args_t* a);
 int theia_gemm_wgrad_pp_mode(const theia_wgrad_args_t* a);
 int theia_wgrad_pp_tiles_shape(int N, int in_c);  // output tiles per tap: 256 x 256, or 128 (n) x 384 (c) where that is less work
+bool theia_wgrad_pp_shape_ok(int M, int N, int in_c);
 
 static bool wgrad_use_pp() {
     static int v = -1;
@@ -610,7 +611,7 @@ static bool wgrad_use_pp() {
 
 extern "C" int theia_wgrad_splits_taps(int M, int N, int kslots, int in_c) {
     const int Ktot = kslots * in_c;
-    if (wgrad_use_pp() && in_c % 64 == 0 && in_c >= 128 && N >= 128) {
+    if (wgrad_use_pp() && theia_wgrad_pp_shape_ok(M, N, in_c)) {
         // ping-pong kernel: 256x256 output tiles (per tap; the last c tile of a tap may be partial), one workgroup per CU -> fill one
         // round of the CU budget as exactly as possible
         const int tiles = theia_wgrad_pp_tiles_shape(N, in_c) * kslots;
@@ -626,7 +627,8 @@ extern "C" int theia_wgrad_splits_taps(int M, int N, int kslots, int in_c) {
         int s = budget / (tiles > 0 ? tiles : 1);
         const int smax = cdiv_i(M, 32) / 8;
         if (s > smax) s = smax;
-        if (s > 64) s = 64;
+        const int cap = N < 128 ? 256 : 64;  // (the skinny, read-bound shapes: one or two tiles, a split per CU is still thousands of rows)
+        if (s > cap) s = cap;
         return s < 1 ? 1 : s;
     }
     const int tiles = cdiv_i(N, 128) * cdiv_i(Ktot, 128);

@@ -449,7 +449,11 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
 }
 
 // in_c a multiple of 64 (the last of ceil(in_c / 256) c tiles may be partial: DeiT-small's 384, DeiT-tiny's 192), at least half a tile of n
-bool theia_gemm_wgrad_pp_supported(const theia_wgrad_args_t* a) { return a->map.in_c % 64 == 0 && a->map.in_c >= 128 && a->N >= 128; }
+// ... or a skinny output over very many rows (round 6: the Depth head's Linear(C, 32) over 64 x 64 maps, M = b * 4096): the launch is bound by
+// reading the [M, in_c] activation once, which the row-streaming ring does at the copy rate with one workgroup per CU (the 2-stage kernel:
+// 280 us for 805 MB); that most of the tile's n columns multiply zeros costs nothing there
+bool theia_wgrad_pp_shape_ok(int M, int N, int in_c) { return in_c % 64 == 0 && in_c >= 128 && (N >= 128 || (N >= 32 && M >= 262144)); }
+bool theia_gemm_wgrad_pp_supported(const theia_wgrad_args_t* a) { return theia_wgrad_pp_shape_ok(a->M, a->N, a->map.in_c); }
 
 // Tile of a launch: 256 (n) x 256 (c), or 128 x 384 (returns 8: NB of the kernel) when that is less MFMA work -- tiles x 0.75 against tiles
 // (N = in_c = 384: 3 x 0.75 against 4; N = 1152, in_c = 384: 9 x 0.75 against 10; multiples of 256 tie and stay).  THEIA_WGRAD_TILE=256 |
