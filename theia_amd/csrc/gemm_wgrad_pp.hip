@@ -98,11 +98,12 @@ __device__ __forceinline__ void wgrad_pp_body(const theia_wgrad_args_t& p, const
     const int ntile = tiles_n * mp.ntaps * tiles_c;
     // hardware places block b on XCD b % 8: give each XCD a contiguous range of (split, tile) so that the workgroups sharing a dY
     // column tile or an activation (tap, c) tile meet in one L2 (THEIA_WGRAD_XCD=0: A/B switch, plain order)
-    // Order inside a split (round 6): c tile slowest, then tap, then n tile.  The ~ntile / (8 / splits) consecutive tiles an XCD gets are
-    // then the taps and n tiles of ONE c tile: every tap of a 3x3 map gathers (a shifted copy of) the same activation pixels, so that
-    // c tile's slice of the gathered operand enters the L2 once instead of once per tap, beside the split's dense rows.  With the tap
-    // slowest (rounds 2-5; plain_order & 2: A/B switch THEIA_WGRAD_XCD=tap) an XCD held ~3 taps x every c tile: the stride-2 launches fetched
-    // 2.8 GB for ~1 GB of operands at 3.4 TB/s (profiles/r05_bench_pmc_traffic.json).
+    // Order inside a split: tap slowest, then c tile, then n tile (plain_order & 2; rounds 2-6).  Round 6 tried the c tile slowest
+    // (THEIA_WGRAD_XCD=ctile: the ~30 consecutive tiles of an XCD are then the taps and n tiles of ONE c tile, whose slice of the gathered
+    // operand every tap reads a shifted copy of): the L2-side fetch of the 3x3 launches fell 18 % (414 -> 340 MB per launch), of the stride-2
+    // launches 6 % (2.78 -> 2.62 GB: the ~30 workgroups of an XCD drift apart by more than the 4 MB L2 holds, the re-reads are served by
+    // the memory-side cache either way) -- and both got 3 % SLOWER (303 vs 295 us, 1283 vs 1251 us, one box): with the tap slowest the
+    // workgroups of an XCD share their dense operand rows, which are the larger stream.  Not the default.
     const int bid = (plain_order & 1) ? hw_bid - first : first == 0 ? gt_xcd_remap(hw_bid, nblocks) : wp_xcd_remap_range(hw_bid, first, nblocks);
     const int tile = bid % ntile, split = bid / ntile;
     const int tn = tile % tiles_n, tk = tile / tiles_n;
@@ -519,7 +520,7 @@ static int wgrad_plain_order() {
     static int plain_order = -1;
     if (plain_order < 0) {
         const char* e = getenv("THEIA_WGRAD_XCD");
-        plain_order = e == nullptr ? 0 : strcmp(e, "0") == 0 ? 1 : strcmp(e, "tap") == 0 ? 2 : 0;
+        plain_order = e == nullptr ? 2 : strcmp(e, "0") == 0 ? 3 : strcmp(e, "ctile") == 0 ? 0 : 2;
     }
     return plain_order;
 }

@@ -266,6 +266,8 @@ class GradBucket:
             self.decay_numel = off
         self.numel = off
         self.flat: Optional[torch.Tensor] = None
+        self._views: Dict[int, torch.Tensor] = {}   # parameter index -> its view of `flat` (built once per buffer: 240 lookups per step)
+        self._views_of: Optional[torch.Tensor] = None
 
     def ensure(self, device) -> torch.Tensor:
         if self.flat is None or self.flat.device != device:
@@ -273,8 +275,13 @@ class GradBucket:
         return self.flat
 
     def view(self, i: int) -> torch.Tensor:
-        p = self.params[i]
-        return self.flat[self.offsets[i]:self.offsets[i] + p.numel()].view(p.shape)
+        if self._views_of is not self.flat:  # (the optimizer / a checkpoint load may have re-pointed the buffer)
+            self._views, self._views_of = {}, self.flat
+        v = self._views.get(i)
+        if v is None:
+            p = self.params[i]
+            v = self._views[i] = self.flat[self.offsets[i]:self.offsets[i] + p.numel()].view(p.shape)
+        return v
 
 
 class StudentEngine:
