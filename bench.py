@@ -473,10 +473,11 @@ def _main(argv=None):
 
     eager_step = step
     if args.graph:
-        if world > 1 or args.no_optimizer:
-            raise SystemExit("--graph: single process, with the optimizer (the captured step is the whole step)")
+        if args.no_optimizer:
+            raise SystemExit("--graph: with the optimizer (the captured step is the whole step)")
         from theia_amd.train_graph import CapturedTrainStep
-        captured = CapturedTrainStep(model, opt, warmup=2)
+        # world > 1: two captured halves with the eager bucket exchange between them (theia_amd/train_graph.py)
+        captured = CapturedTrainStep(ddp if world > 1 else model, opt, warmup=2)
         # the synthetic batch lives in the step's static input buffers (what a data pipeline that ingests straight into them does): the
         # eager loop reads its resident batch in place too
         xs, ys = captured.static_inputs(images, targets)
@@ -709,7 +710,7 @@ def _main(argv=None):
             "config": {"workload": f"{args.backbone.split('/')[-1]} student + {len(TEACHERS)} teacher{'s' if len(TEACHERS) > 1 else ''} ({args.teachers}), per-GPU batch {b}, "
                                    f"teacher features resident as {'bf16' if teacher_dtype == torch.bfloat16 else 'fp32'}, "
                                    f"loss 0.9*cos+0.1*smoothL1, step = fwd+loss+bwd+grad all-reduce" +
-                                   ("" if args.no_optimizer else "+fused AdamW") + (", one hipGraph replay per step" if args.graph else ""),
+                                   ("" if args.no_optimizer else "+fused AdamW") + ((", one hipGraph replay per step" if world == 1 else ", two hipGraph replays per step around the eager gradient exchange") if args.graph else ""),
                        "global_batch": b * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
             "settle_steps": settle_steps,
             "host_enqueue_ms_per_step": round(host_dt * 1e3, 3),

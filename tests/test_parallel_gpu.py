@@ -205,3 +205,96 @@ def test_dp2_on_one_gpu_matches_single_process_gradient():
     assert ret["n"] > 100
     name, err = ret["worst"]
     assert err < 2e-4, (name, err)
+
+
+def _captured_worker(rank, world, port, ret, backend="gloo"):
+    """world-size-2 job on the captured step (round 6): every rank runs CapturedTrainStep(TheiaDataParallel(model), FusedAdamW) -- graph A,
+    the eager bucket exchange through the real GradBucketReducer, graph B -- for 5 steps (2 eager warm-up calls, capture, 3 replays) on its
+    half of the batch; rank 0 compares the loss trajectory (mean over the ranks) with a single-process eager loop on the whole batch."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from oracle import theia_oracle as O  # checker only (synthetic inputs)
+    from theia_amd.foundation_models.common import get_model_feature_size
+    from theia_amd.models.rvfm import RobotVisionFM
+    from theia_amd.optimizers import FusedAdamW
+    from theia_amd.parallel import TheiaDataParallel
+    from theia_amd.train_graph import CapturedTrainStep
+
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    bb, teachers = "facebook/deit-tiny-patch16-224", O.TEACHER_SETS["dinov2"]
+
+    def build():
+        m = RobotVisionFM(backbone=bb, translator="lconv", translator_kwargs={"hidden_size_factor": 1.0},
+                          target_feature_sizes={t: get_model_feature_size(t, keep_spatial=True) for t in teachers}, precision="fp32")
+        m.load_state_dict(O.synth_params(bb, teachers, 0))
+        return m.to(dev)
+
+    model = build()
+    ddp = TheiaDataParallel(model)
+    opt = FusedAdamW(ddp, lr=1e-3, weight_decay=0.01)
+    step = CapturedTrainStep(ddp, opt, grad_clip=0.5, warmup=2)
+    assert step.split and step.reducer is ddp.reducer
+    B, per, nsteps = 4, 2, 5
+    sl = slice(rank * per, (rank + 1) * per)
+    mine = []
+    for i in range(nsteps):
+        images = O.synth_images(B, i)
+        targets = O.synth_targets(B, teachers, 100 + i)
+        mine.append(float(step(images[sl].to(dev), {t: v[sl].to(dev) for t, v in targets.items()})["main_loss"]))
+    torch.cuda.synchronize()
+    both = torch.tensor(mine, dtype=torch.float64)
+    dist.all_reduce(both)  # (every loss term is a batch mean: the mean of the ranks' losses is the whole-batch loss)
+    both /= world
+    if rank == 0:
+        ref = build()
+        oref = FusedAdamW(ref, lr=1e-3, weight_decay=0.01)
+        want = []
+        for i in range(nsteps):
+            images = O.synth_images(B, i).to(dev)
+            targets = {t: v.to(dev) for t, v in O.synth_targets(B, teachers, 100 + i).items()}
+            oref.zero_grad(set_to_none=True)
+            ls = ref.get_loss(ref(images), targets, as_float=False)
+            main = 0.9 * ls["cos_loss"] + 0.1 * ls["l1_loss"]
+            main.backward()
+            oref.clip_grad_norm_(0.5)
+            oref.step()
+            want.append(float(main))
+        torch.cuda.synchronize()
+        # Parameters are compared through the losses they produce: Adam's first steps move every weight by ~lr whatever the size of its
+        # gradient, so entries whose gradient is rounding noise (dead ReLU regions) walk off in either direction -- 2e-2 of a tensor's
+        # scale after 5 steps, in the eager dp tests just as here -- while every step's loss is a function of all parameters
+        ret["worst"] = max(abs(a - b) / abs(b) for a, b in zip(both.tolist(), want))
+        ret["losses"] = (both.tolist(), want)
+        ret["replays"] = step.replays
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@one_gpu_rig
+def test_captured_halves_with_the_gradient_exchange_two_ranks_on_one_gpu():
+    """the world-size > 1 form of the captured step, executed: two ranks (sharing the one GPU, gloo) x 2 images against one process x 4
+    images, 5 AdamW steps with clipping -- the mean of the two half-batch gradients is the whole-batch gradient (golden G9), so the
+    parameters agree to fp32 rounding amplified by Adam (same bound as the eager dp2 tests use for gradients, per step)"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_captured_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    print(f"[captured halves, world 2] replays {ret['replays']}, losses (mean of the ranks) {[round(v, 6) for v in ret['losses'][0]]} vs one "
+          f"process {[round(v, 6) for v in ret['losses'][1]]}: worst relative deviation {ret['worst']:.2e}")
+    assert ret["replays"] == 3 and ret["worst"] < 1e-4 and ret["losses"][1][-1] < ret["losses"][1][0], dict(ret)
+
+
+@two_gpus
+def test_captured_halves_with_the_gradient_exchange_rccl():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_captured_worker, args=(2, _free_port(), ret, "nccl"), nprocs=2, join=True)
+    assert ret["replays"] == 3 and ret["worst"] < 1e-4, dict(ret)

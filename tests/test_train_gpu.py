@@ -248,8 +248,25 @@ def test_train_script_with_grad_clip(tmp_path):
     assert len(seen) == 10 and len(tl) == 2 and all(v == v for v in tl) and tl[-1] < tl[0]
 
 
-@pytest.mark.parametrize("precision,grad_clip", [("bf16", None), ("fp32", 0.5), ("bf16", 0.05)])
-def test_captured_train_step_is_bit_identical_to_the_eager_loop(precision, grad_clip):
+class _CountingReducer:
+    """stands in for parallel.GradBucketReducer at 'world size 2' on one GPU: records what the captured step hands it (the real exchange
+    needs a second rank; its collectives are covered by tests/test_parallel_gloo.py and tests/test_parallel_gpu.py)"""
+    world = 2
+
+    def __init__(self):
+        self.calls, self.finishes = [], 0
+
+    def bucket_ready(self, flat, also_after=None):
+        assert not torch.cuda.is_current_stream_capturing()  # the exchange is eager, BETWEEN the captured halves
+        self.calls.append(flat.data_ptr())
+
+    def finish(self):
+        self.finishes += 1
+
+
+@pytest.mark.parametrize("precision,grad_clip,split", [("bf16", None, False), ("fp32", 0.5, False), ("bf16", 0.05, False),
+                                                         ("bf16", None, True), ("bf16", 0.05, True), ("fp32", 0.5, "reducer")])
+def test_captured_train_step_is_bit_identical_to_the_eager_loop(precision, grad_clip, split):
     """theia_amd/train_graph.py: zero_grad + forward + losses + backward (+ clipping) + fused AdamW + operand rebuild captured into one
     hipGraph.  Two identically initialised models, the same 6 batches, a learning rate that changes every step (the scheduler's job):
     the eager loop (host-side optimizer scalars) and the captured step (2 eager warm-up calls, then capture + 4 replays; scalars read
@@ -260,7 +277,15 @@ def test_captured_train_step_is_bit_identical_to_the_eager_loop(precision, grad_
     mb, _ = _build(precision)
     oa = FusedAdamW(ma, lr=1e-3, weight_decay=0.01)
     ob = FusedAdamW(mb, lr=1e-3, weight_decay=0.01)
-    step_b = CapturedTrainStep(mb, ob, grad_clip=grad_clip, warmup=2)
+    # split (round 6): the form a world-size > 1 job runs -- graph A (zero_grad .. backward), the eager gradient-bucket exchange, graph B
+    # (clipping, AdamW, operand rebuild).  With no second rank the exchange is a no-op (split=True) or a recording stub ("reducer"): the
+    # step must stay bit-identical to the eager loop, and every bucket must pass through the reducer exactly once per step, outside
+    # any capture, with the engine's per-bucket hook restored afterwards
+    red = _CountingReducer() if split == "reducer" else None
+    hook_seen = []
+    if red is not None:
+        mb.engine.bucket_ready_hook = lambda b, ev=None: hook_seen.append(b.name)  # what TheiaDataParallel installs at world > 1
+    step_b = CapturedTrainStep(mb, ob, grad_clip=grad_clip, warmup=2, split=bool(split), reducer=red)
     B = 4
     for i in range(6):
         images = O.synth_images(B, i).to("cuda:0")
@@ -287,6 +312,11 @@ def test_captured_train_step_is_bit_identical_to_the_eager_loop(precision, grad_
         for (ka, pa), (_kb, pb) in zip(ma.named_parameters(), mb.named_parameters()):
             assert torch.equal(pa, pb), (i, ka)
     assert step_b.replays == 4 and oa.step_count == ob.step_count == 6
+    if red is not None:
+        nb = len([b for b in mb.engine.buckets if b.flat is not None])
+        assert red.finishes == 6 and len(red.calls) == 6 * nb and red.calls[:nb] == [b.flat.data_ptr() for b in mb.engine.buckets if b.flat is not None]
+        assert hook_seen == [] and mb.engine.bucket_ready_hook is not None  # never fired inside a half; restored after each
+        mb.engine.bucket_ready_hook = None
     # the replays changed the parameters behind the host's back: an eager call afterwards must rebuild its operands from them
     with torch.no_grad():
         fa = ma.forward_feature(images)

@@ -102,15 +102,18 @@ def train(rvfm: nn.Module, target_model_names, optimizer, lr_scheduler, train_it
     log_interval = int(cfg.logging.get("log_interval", 10))
     steps = 0
     history = {"train_main_loss": [], "eval_main_loss": []}
-    # training.capture_step=true (no reference equivalent; single process): the loop body below -- forward, get_loss, backward, clipping,
-    # optimizer.step -- runs as ONE hipGraph replay per step (theia_amd/train_graph.py); it pays where the eager loop is host-bound,
-    # i.e. at the reference's default per-GPU batch of 16 (configs/training/frame_level.yaml:8)
+    # training.capture_step=true (no reference equivalent): the loop body below -- forward, get_loss, backward, clipping, optimizer.step --
+    # runs as ONE hipGraph replay per step, or, under torchrun with world size > 1, as two replays around the eager gradient-bucket
+    # exchange (theia_amd/train_graph.py); it pays where the eager loop is host-bound, i.e. at the reference's default per-GPU batch
+    # of 16 (configs/training/frame_level.yaml:8)
     captured = None
     if cfg.training.get("capture_step", False):
-        if (dist.is_initialized() and dist.get_world_size() > 1) or not isinstance(optimizer, FusedAdamW):
-            raise NotImplementedError("training.capture_step needs a single process and the fused optimizer")
+        if not isinstance(optimizer, FusedAdamW):
+            raise NotImplementedError("training.capture_step needs the fused optimizer")
         from theia_amd.train_graph import CapturedTrainStep
-        captured = CapturedTrainStep(rvfm.module, optimizer, main_loss=lambda l: select_main_loss(l, cfg.training.main_loss), warmup=2)
+        multi = dist.is_initialized() and dist.get_world_size() > 1
+        captured = CapturedTrainStep(rvfm if multi else rvfm.module, optimizer, main_loss=lambda l: select_main_loss(l, cfg.training.main_loss),
+                                     warmup=2)
     for ep in range(cfg.training.epochs):
         rvfm.train()
         t0 = time.time()

@@ -13,8 +13,15 @@ corrections) -- ``theia_adamw_step_dev`` reads them from a 3-float device tensor
 every replay; the clip coefficient already was device-resident.  Inputs are copied into static buffers in front of the replay;
 the losses come back as 0-d device tensors (reading them is the caller's synchronisation, as with ``get_loss(as_float=False)``).
 
-Single process only: with world size > 1 the gradient exchange (RCCL on a side stream, CU budget switching) stays eager -- use the
-plain loop there.  fp8 mode (host-side calibration of the first use of every scale slot) is not capturable either.
+World size > 1 (round 6): the step is captured as TWO halves with the gradient exchange between them --
+    graph A  zero_grad, forward, losses, backward (every gradient bucket complete; the engine's per-bucket hook is off inside)
+    eager    the bucket exchange of theia_amd/parallel.py (RCCL, the same ``GradBucketReducer`` calls as the plain loop, in bucket order)
+    graph B  clipping, fused AdamW, operand rebuild
+-- three host calls + one collective per bucket instead of ~1500 launches.  The exchange does not overlap the backward pass in this mode; it
+is for the host-bound regime the capture exists for (the reference's default per-GPU batch of 16, train_rvfm.py:211-213,258 with
+frame_level.yaml:8: a DeiT-small / cdiv step is ~7.5 ms of GPU time and ~100 MB of gradients, ~1 ms over xGMI).  ``split=True`` forces the
+two-half form in a single process (what the bit-identity test runs: the exchange is then a no-op).
+fp8 mode (host-side calibration of the first use of every scale slot) is not capturable.
 """
 from __future__ import annotations
 
@@ -38,10 +45,20 @@ class CapturedTrainStep:
     Returns the dict of ``get_loss(..., as_float=False)`` plus ``"main_loss"`` (and ``"grad_norm"`` with clipping): device tensors that
     are overwritten by the next call.  A change of input shapes re-captures."""
 
-    def __init__(self, model, optimizer, main_loss: Callable = default_main_loss, grad_clip: Optional[float] = None, warmup: int = 2):
+    def __init__(self, model, optimizer, main_loss: Callable = default_main_loss, grad_clip: Optional[float] = None, warmup: int = 2,
+                 split: Optional[bool] = None, reducer=None):
+        """model: the ``RobotVisionFM``, or the ``TheiaDataParallel`` wrapper around it (world size > 1: its reducer exchanges the buckets
+        between the two captured halves; ``reducer`` passes one explicitly).  split: None = two halves iff a reducer with world > 1."""
+        if hasattr(model, "reducer") and hasattr(model, "module"):  # TheiaDataParallel
+            reducer = reducer if reducer is not None else model.reducer
+            model = model.module
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            raise NotImplementedError("CapturedTrainStep: single-process only (the gradient exchange of theia_amd/parallel.py stays eager)")
+        if reducer is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise ValueError("CapturedTrainStep at world size > 1 needs the TheiaDataParallel wrapper (or its reducer): the gradient "
+                             "buckets are exchanged between the two captured halves of the step")
+        self.reducer = reducer
+        self.split = bool(split) if split is not None else (reducer is not None and reducer.world > 1)
+        self._graph_b = None
         if getattr(model, "precision", None) == "fp8":
             raise NotImplementedError("CapturedTrainStep: fp8 mode calibrates its scale slots from the host and is not capturable")
         self.model, self.opt, self.main_loss, self.grad_clip, self.warmup = model, optimizer, main_loss, grad_clip, max(1, int(warmup))
@@ -68,6 +85,38 @@ class CapturedTrainStep:
     def invalidate(self) -> None:
         """void the capture (e.g. after ``freeze_translator()``: which parameters have gradients is baked into the captured step)"""
         self._graph = None
+
+    # ------------------------------------------------------------------ the two halves (world size > 1, or split=True)
+    def _body_a(self) -> Dict[str, Any]:
+        """zero_grad .. backward.  The engine's per-bucket hook (TheiaDataParallel: start the bucket's exchange on the side stream) must
+        not fire inside a capture: the buckets are exchanged behind this half, eagerly."""
+        eng = self.model.engine
+        hook, eng.bucket_ready_hook = eng.bucket_ready_hook, None
+        try:
+            self.opt.zero_grad(set_to_none=True)
+            pred = self.model(self._x)
+            losses = self.model.get_loss(pred, self._y, as_float=False)
+            main = self.main_loss(losses)
+            main.backward()
+        finally:
+            eng.bucket_ready_hook = hook
+        out = dict(losses)
+        out["main_loss"] = main.detach()
+        return out
+
+    def _exchange(self) -> None:
+        """every gradient bucket through the reducer (backward-completion order), then wait on this stream -- eager, every step"""
+        if self.reducer is None or self.reducer.world == 1:
+            return
+        for b in self.model.engine.buckets:
+            if b.flat is not None:
+                self.reducer.bucket_ready(b.flat)
+        self.reducer.finish()
+
+    def _body_b(self, out: Dict[str, Any]) -> None:
+        if self.grad_clip is not None:
+            out["grad_norm"] = self.opt.clip_grad_norm_(self.grad_clip)
+        self.opt.step()
 
     # ------------------------------------------------------------------ the step itself (eager and captured: the same code)
     def _body(self) -> Dict[str, Any]:
@@ -103,6 +152,42 @@ class CapturedTrainStep:
             if v is not self._y[t]:
                 self._y[t].copy_(v, non_blocking=True)
 
+    def _capture(self, fn):
+        """fn() captured on self.stream, single-stream (see __call__); -> (graph, what fn returned)"""
+        sq = getattr(self.model.engine, "_sideq", None)
+        was = None
+        if sq is not None:
+            sq.join()
+            was, sq.enabled = sq.enabled, False
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream):
+                ret = fn()
+        finally:
+            if sq is not None:
+                sq.enabled = was
+        return g, ret
+
+    def _call_split(self) -> None:
+        from . import engine as _eng
+        if self.calls <= self.warmup:
+            self._out = self._body_a()
+            self._exchange()
+            self._body_b(self._out)
+            return
+        if self._graph is None:
+            self._graph, self._out = self._capture(self._body_a)
+            self._graph_b = None
+        self._graph.replay()
+        self._exchange()
+        if self._graph_b is None:
+            # (captured after graph A has run once: the gradient buffers and the clip scratch exist; capturing B does not execute it)
+            self._graph_b, _ = self._capture(lambda: self._body_b(self._out))
+        self._graph_b.replay()
+        self.opt._prepared = False
+        self.replays += 1
+        _eng.PARAM_EPOCH[0] += 1
+
     def __call__(self, images: torch.Tensor, targets: Dict[str, torch.Tensor]) -> Dict[str, Any]:
         if images.dtype != torch.uint8 or images.dim() != 4:
             raise TypeError("CapturedTrainStep takes a uint8 [B, H, W, 3] / [B, 3, H, W] image batch")
@@ -113,7 +198,9 @@ class CapturedTrainStep:
         with torch.cuda.stream(self.stream):
             self._stage_inputs(images, targets)
             self.opt.prepare_step()
-            if self.calls <= self.warmup:
+            if self.split:
+                self._call_split()
+            elif self.calls <= self.warmup:
                 self._out = self._body()
             else:
                 if self._graph is None:
