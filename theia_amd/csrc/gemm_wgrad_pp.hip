@@ -78,9 +78,14 @@ __device__ __forceinline__ int wp_xcd_remap_range(int b, int first, int n) {
 
 // The body of one workgroup: block `hw_bid` (its blockIdx.x: hw_bid % 8 is the XCD it runs on) of the blocks [first, first + nblocks) that
 // problem p owns in the launch (first = 0: a launch of its own).
-template <bool FAST, bool SPLIT_ISSUE, int NSTAGE, int MODE, int NB = 16>
+template <bool FAST, bool SPLIT_ISSUE, int NSTAGE, int MODE, int NB = 16, bool BOTH_R = false>
 __device__ __forceinline__ void wgrad_pp_body(const theia_wgrad_args_t& p, const int plain_order, const int hw_bid, const int nblocks, const int first = 0) {
     constexpr bool wgrad_split_issue = SPLIT_ISSUE;
+    // BOTH_R (round 6): both rows of half-step h+AHEAD issued in the R segment, none between the MFMAs (what the NT kernel does).  Pays for
+    // the stepping row mode only, whose ~35 VALU per staged row between the MFMAs held the matrix pipe up: the stride-2 launches 1273 ->
+    // 1164 us isolated, the step -0.1 ms; the periodic mode got slower (304 -> 338 us: its R segment then outlasts the other group's M),
+    // plain matrices the same, and the 128 x 384 tile (24 MFMAs per M segment) prefers the split too.
+    constexpr bool both_r = BOTH_R && SPLIT_ISSUE;
     constexpr bool V = NB == 8;  // the 128 x 384 tile
     static_assert(NB == 16 || (NB == 8 && FAST && SPLIT_ISSUE), "the 128 x 384 tile: stepping instantiations with the split issue only");
     constexpr int TN = V ? 128 : 256, TC = V ? 384 : 256, WC = V ? 96 : 128;  // tile columns (n, c), c columns per wave
@@ -356,9 +361,11 @@ __device__ __forceinline__ void wgrad_pp_body(const theia_wgrad_args_t& p, const
             // issue cycles each) + ~40 VALU.  With both in the M segment it was ~1200 cycles against ~600 for R -- the matrix pipe 40 %
             // busy (PMC) -- since the other group's R segment cannot run longer than this group's M; one in each balances them.
             if (wgrad_split_issue) issue_row(0, nslot);
+            if (both_r) issue_row(1, nslot);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // half-step h+1 landed; h+2 .. h+AHEAD-1 (4 operations each) and, when issued above, row 0 of h+AHEAD (2) may still be in flight
-            if (wgrad_split_issue) wp_wait_vm<(AHEAD - 2) * 4 + 2>();
+            if (both_r) wp_wait_vm<(AHEAD - 2) * 4 + 4>();
+            else if (wgrad_split_issue) wp_wait_vm<(AHEAD - 2) * 4 + 2>();
             else wp_wait_vm<(AHEAD - 2) * 4>();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -370,7 +377,7 @@ __device__ __forceinline__ void wgrad_pp_body(const theia_wgrad_args_t& p, const
 #pragma unroll
                 for (int i = 0; i < FN; ++i) GtMma<bf16_t>::run(acc[i][j], fa[j], fb[i]);
                 if (!wgrad_split_issue && j == 0) issue_row(0, nslot);
-                if (j == (wgrad_split_issue ? 2 : 4)) issue_row(1, nslot);
+                if (!both_r && j == (wgrad_split_issue ? 2 : 4)) issue_row(1, nslot);
             }
             if (do_bias) {
 #pragma unroll
@@ -411,9 +418,9 @@ __device__ __forceinline__ void wgrad_pp_body(const theia_wgrad_args_t& p, const
     }
 }
 
-template <bool FAST, bool SPLIT_ISSUE = true, int NSTAGE = 4, int MODE = 0, int NB = 16>
+template <bool FAST, bool SPLIT_ISSUE = true, int NSTAGE = 4, int MODE = 0, int NB = 16, bool BOTH_R = false>
 __global__ __launch_bounds__(512) void gemm_wgrad_pp_kernel(const theia_wgrad_args_t p, const int plain_order) {
-    wgrad_pp_body<FAST, SPLIT_ISSUE, NSTAGE, MODE, NB>(p, plain_order, (int)blockIdx.x, (int)gridDim.x);
+    wgrad_pp_body<FAST, SPLIT_ISSUE, NSTAGE, MODE, NB, BOTH_R>(p, plain_order, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Grouped launch (round 6): up to WGRAD_GROUP_MAX plain-matrix problems (mode 1: the nn.Linear weight gradients) in ONE grid.  Why: a
@@ -582,6 +589,7 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true, true, 5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds5);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_pp_kernel<true, true, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_wgrad_pp_kernel<true, true, 4, 0, 8>)), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_wgrad_pp_kernel<true, true, 4, 0, 16, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_wgrad_pp_kernel<true, true, 4, 1, 8>)), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_wgrad_pp_kernel<true, true, 4, 2, 8>)), hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
         attr_set = true;
@@ -600,6 +608,11 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
     }
     const int plain_order = wgrad_plain_order();
     const int mode = theia_gemm_wgrad_pp_mode(a);
+    static int issue_r = -1;  // stepping row mode: both rows in the R segment (THEIA_WGRAD_ISSUE=split: A/B switch, one in each)
+    if (issue_r < 0) {
+        const char* e = getenv("THEIA_WGRAD_ISSUE");
+        issue_r = (e != nullptr && strcmp(e, "split") == 0) ? 0 : 1;
+    }
     const dim3 grid(tiles * a->splits);
     if (nb == 8 && mode == 11) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 1, 8>), grid, dim3(512), lds4, stream, *a, plain_order);
     else if (nb == 8 && mode == 12) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 2, 8>), grid, dim3(512), lds4, stream, *a, plain_order);
@@ -609,6 +622,7 @@ int theia_gemm_wgrad_pp_launch(const theia_wgrad_args_t* a, hipStream_t stream) 
     else if (mode == 12) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 2>), grid, dim3(512), lds4, stream, *a, plain_order);
     else if (mode == 10 && issue_in_m) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, false>), grid, dim3(512), lds4, stream, *a, plain_order);
     else if (mode == 10 && stages == 5) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 5>), grid, dim3(512), lds5, stream, *a, plain_order);
+    else if (mode == 10 && issue_r) hipLaunchKernelGGL((gemm_wgrad_pp_kernel<true, true, 4, 0, 16, true>), grid, dim3(512), lds4, stream, *a, plain_order);
     else if (mode == 10) hipLaunchKernelGGL(gemm_wgrad_pp_kernel<true>, grid, dim3(512), lds4, stream, *a, plain_order);
     else hipLaunchKernelGGL(gemm_wgrad_pp_kernel<false>, grid, dim3(512), lds4, stream, *a, plain_order);
     THEIA_CHECK_LAUNCH("theia_gemm_wgrad(pp)");
