@@ -118,6 +118,38 @@ def test_fused_adamw_leaves_frozen_parameters_alone():
             assert torch.allclose(p, pb[k], rtol=2e-3, atol=2e-5), k
 
 
+def test_grouped_weight_gradients_with_frozen_layers_match_the_ungrouped_launches(monkeypatch):
+    """The grouped weight-gradient launch of a layer (bf16; DeiT-tiny: all four ViT gradients wait for the q/k/v one) with parameters frozen in
+    every way the grouping has to cope with: o_proj frozen entirely (left out of the group), one q_proj weight frozen (the fused q/k/v path
+    bails out: every pending gradient falls back to its own launch), fc2's bias alone frozen (that layer's fc2 takes its own launch, the rest
+    is grouped).  Against the same model with THEIA_WGRAD_GROUP=0: same gradients (another split of the f32 row sums), frozen ones absent."""
+    ma, teachers = _build("bf16")
+    mb, _ = _build("bf16")
+    frozen = ("backbone.model.layers.3.attention.o_proj.weight", "backbone.model.layers.3.attention.o_proj.bias",
+              "backbone.model.layers.6.attention.q_proj.weight", "backbone.model.layers.9.mlp.fc2.bias")
+    for m in (ma, mb):
+        for k, p in m.named_parameters():
+            if k in frozen:
+                p.requires_grad = False
+    images = O.synth_images(4, 0)
+    targets = {t: v.to("cuda:0") for t, v in O.synth_targets(4, teachers, 1).items()}
+    grads = []
+    for m, mode in ((ma, "auto"), (mb, "0")):
+        monkeypatch.setenv("THEIA_WGRAD_GROUP", mode)
+        losses = m.get_loss(m(images), targets, as_float=False)
+        (0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]).backward()
+        torch.cuda.synchronize()
+        grads.append({k: (None if p.grad is None else p.grad.detach().clone()) for k, p in m.named_parameters()})
+    ga, gb = grads
+    for k in ga:
+        if k in frozen:
+            assert ga[k] is None and gb[k] is None, k
+        else:
+            assert ga[k] is not None and gb[k] is not None, k
+            d = float((ga[k] - gb[k]).abs().max()) / (float(gb[k].abs().max()) + 1e-30)
+            assert d < 1e-3, (k, d)
+
+
 def test_reference_lr_schedulers_drive_fused_adamw():
     """FusedAdamW is a torch.optim.Optimizer: both reference schedules (lr_schedulers.py:8-77) produce the same LR sequence
     on it as on torch.optim.AdamW -- in particular the cosine one is not silently replaced by a constant."""
