@@ -226,6 +226,20 @@ size_t theia_colsum_workspace_bytes(int64_t M, int N);
 int theia_quantize_fp8(const void* src, int src_dtype, int64_t rows, int C, int64_t ld, uint8_t* dst, const float* scale, float* amax,
                        void* stream);
 int theia_fp8_update_scales(float* amax, float* scale, float* inv_scale, int n, float margin, void* stream);
+/* v11: the same quantisation for a whole table of contiguous bf16 tensors in ONE launch (the e4m3 copies of every GEMM weight operand after
+ * an optimizer step).  theia_quantize_fp8_batch_plan fills first_block of a HOST table and returns the grid size (< 0: bad table); the table
+ * is then copied to the device once and reused while pointers and sizes stay the same. */
+typedef struct {
+    const void* src;    /* bf16 [n], contiguous */
+    uint8_t* dst;       /* e4m3 [n] */
+    const float* scale; /* device scalar */
+    float* amax;        /* device scalar, or NULL */
+    int64_t n;          /* elements, a multiple of 8 */
+    int32_t first_block;
+    int32_t pad_;
+} theia_quant_job_t;
+int64_t theia_quantize_fp8_batch_plan(theia_quant_job_t* jobs_host, int njobs);
+int theia_quantize_fp8_batch(const theia_quant_job_t* jobs_device, int njobs, int64_t total_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Parameter preparation (fp32 master weights in the reference state_dict layout -> operand layouts)

@@ -63,6 +63,11 @@ class CastJob(C.Structure):
     ]
 
 
+class QuantJob(C.Structure):  # theia_quant_job_t
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("scale", C.c_void_p), ("amax", C.c_void_p), ("n", C.c_int64),
+                ("first_block", C.c_int32), ("pad_", C.c_int32)]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [
         ("dy", C.c_void_p), ("a", C.c_void_p), ("slabs", C.c_void_p),
@@ -99,6 +104,8 @@ _SIGNATURES = {
     "theia_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "theia_quantize_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "theia_fp8_update_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "theia_quantize_fp8_batch_plan": (C.c_int64, [C.c_void_p, C.c_int]),
+    "theia_quantize_fp8_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "theia_colsum_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "theia_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "theia_cast_batch_plan": (C.c_int64, [C.c_void_p, C.c_int]),

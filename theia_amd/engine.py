@@ -299,6 +299,8 @@ class StudentEngine:
         self.geo224 = Geometry(GRID, GRID, self.tok0, self.nreg, False)
         self._interp: Dict[Any, Any] = {}
         self._opcache: Dict[str, torch.Tensor] = {}
+        self._fp8_wbatch = None  # ops.QuantBatch over the weight operands (built with the operand table)
+        self._fp8_conv_bf16: Dict[Any, bool] = {}  # fp8 mode: (weight key, M) -> this convolution stays on the bf16 3x3 kernel
         self._opkey = None
         self._op_ptr_key = None
         self._opbatch = None
@@ -466,15 +468,25 @@ class StudentEngine:
             self._op_ptr_key = ptr_key
             if self.precision == "fp8":
                 self.fp8 = Fp8Scales(device)
+                self._fp8_wbatch = None
         self._opbatch.run()
         if self.fp8 is not None:
             # delayed scaling: last step's maxima become this step's scales; then the e4m3 copies of every GEMM weight operand
             # (forward W and data-gradient W^T / packed convolution weights) are re-quantised from their bf16 operands
             self.fp8.update()
-            for k in [k for k, t in self._opcache.items() if t.dtype == torch.bfloat16 and t.dim() == 2 and not k.endswith(".f8")
-                      and t.shape[1] % 64 == 0 and t.shape[0] >= 64 and k != "patch.w"]:
-                q, inv = self.fp8.quantize(self._opcache[k], "w:" + k)
-                self._opcache[k + ".f8"], self._opcache[k + ".inv"] = q, inv
+            if self._fp8_wbatch is None:
+                # first build: every weight slot calibrates itself (max-only pass, then its scale) and gets its persistent e4m3 buffer;
+                # from then on ONE launch re-quantises all of them (round 6: they were ~130 launches of a few us per step)
+                qb = ops.QuantBatch(device)
+                for k in [k for k, t in self._opcache.items() if t.dtype == torch.bfloat16 and t.dim() == 2 and not k.endswith(".f8")
+                          and t.shape[1] % 64 == 0 and t.shape[0] >= 64 and k != "patch.w" and t.is_contiguous()]:
+                    q, inv = self.fp8.quantize(self._opcache[k], "w:" + k)
+                    self._opcache[k + ".f8"], self._opcache[k + ".inv"] = q, inv
+                    i = self.fp8.slot("w:" + k)
+                    qb.add(self._opcache[k], q, self.fp8.scale[i:i + 1], self.fp8.amax[i:i + 1])
+                self._fp8_wbatch = qb
+            else:
+                self._fp8_wbatch.run()
         self._opkey = key
         return self._opcache
 
@@ -862,7 +874,7 @@ class StudentEngine:
         """sums: zeroed f32 [b, 2]; every launch (4 output-parity classes for a stride-2 transposed convolution) adds the per-sample
         (sum, sum of squares) of what it stores: the statistics of the whole-sample LayerNorm that follows."""
         C = self.D
-        wf, scale_inv = self._conv_operands(x, wf)
+        wf, scale_inv = self._conv_operands(x, wf, None if len(plan.fwd) > 1 else (plan.fwd[0][0], b * plan.fwd[0][1], out))
         if scale_inv is not None:
             x = scale_inv[2]
         for rmap, mpi in plan.fwd:
@@ -870,10 +882,22 @@ class StudentEngine:
                         ln_sums=sums, scale_inv=scale_inv[:2] if scale_inv is not None else None)
         return out
 
-    def _conv_operands(self, x: torch.Tensor, wkey: str):
+    def _conv_operands(self, x: torch.Tensor, wkey: str, launch=None):
         """(weight operand, None) -- or in fp8 mode (e4m3 weight, (inv_x, inv_w, e4m3 activation)): the activation (any NHWC /
-        token layout with C channels innermost) is quantised as a [rows, C] matrix, the row map addresses it unchanged"""
+        token layout with C channels innermost) is quantised as a [rows, C] matrix, the row map addresses it unchanged.
+        launch = (row map, M, out) of a single-launch convolution: when the bf16 launch would run on the one-image-per-tile 3x3 kernel
+        (gemm_conv_pp: 1.25-1.5 PF, faster than the generic NT kernel is on e4m3 operands) it keeps its bf16 operands in fp8 mode too --
+        no quantisation pass for its input either (round 6)."""
         oc = self._opcache
+        if self.fp8 is not None and launch is not None:
+            rmap, M, out = launch
+            key = (wkey, M)
+            keep = self._fp8_conv_bf16.get(key)
+            if keep is None:
+                C = self.D
+                keep = self._fp8_conv_bf16[key] = ops.gemm_nt(x, oc[wkey], out, M, C, rmap.ntaps * C, rmap, 9 * C, C, plan_only=True) == 256009
+            if keep:
+                return oc[wkey], None
         if self.fp8 is not None and wkey + ".f8" in oc and x.numel() // self.D < (1 << 22):  # (output rows <= 4x input rows < 2^24: see _mm)
             x8, inv = self.fp8.quantize(x.reshape(-1, self.D), "x:" + wkey)
             return oc[wkey + ".f8"], (inv, oc[wkey + ".inv"], x8)
@@ -1002,7 +1026,7 @@ class StudentEngine:
 
             def conv_dgrad(dy, wd_key, plan, out, resid=None):
                 rmap, mpi = plan.dgrad
-                wd, scale_inv = self._conv_operands(dy, wd_key)
+                wd, scale_inv = self._conv_operands(dy, wd_key, (rmap, b * mpi, out))
                 ops.gemm_nt(dy if scale_inv is None else scale_inv[2], wd, out, b * mpi, C, 9 * C, rmap, 9 * C, C, resid=resid,
                             scale_inv=scale_inv[:2] if scale_inv is not None else None)
                 return out

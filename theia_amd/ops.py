@@ -214,6 +214,40 @@ def quantize_fp8(x: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tens
     return out
 
 
+class QuantBatch:
+    """A table of fp8 quantisations of contiguous bf16 tensors executed by ONE launch (theia_quantize_fp8_batch): the e4m3 copies of
+    every GEMM weight operand, rebuilt after each optimizer step.  add() while building, then run() any number of times; bound to the
+    data pointers it was built with."""
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs: List[N.QuantJob] = []
+        self._dev: Optional[torch.Tensor] = None
+        self._blocks = 0
+        self._keep: List[torch.Tensor] = []
+
+    def add(self, src: torch.Tensor, dst: torch.Tensor, scale: torch.Tensor, amax: torch.Tensor) -> None:
+        assert src.dtype == torch.bfloat16 and src.is_contiguous() and dst.is_contiguous() and dst.numel() == src.numel() and src.numel() % 8 == 0
+        assert self._dev is None
+        j = N.QuantJob()
+        j.src, j.dst, j.scale, j.amax, j.n = src.data_ptr(), dst.data_ptr(), scale.data_ptr(), amax.data_ptr(), src.numel()
+        self.jobs.append(j)
+        self._keep += [src, dst, scale, amax]
+
+    def run(self) -> None:
+        if not self.jobs:
+            return
+        if self._dev is None:
+            import ctypes
+            arr = (N.QuantJob * len(self.jobs))(*self.jobs)
+            self._blocks = N.lib().theia_quantize_fp8_batch_plan(ctypes.addressof(arr), len(self.jobs))
+            if self._blocks <= 0:
+                raise N.TheiaNativeError("theia_quantize_fp8_batch_plan: bad job table")
+            raw = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr))), dtype=torch.uint8)
+            self._dev = raw.to(self.device)
+        N.check(N.lib().theia_quantize_fp8_batch(self._dev.data_ptr(), len(self.jobs), self._blocks, N.stream_ptr()), "theia_quantize_fp8_batch")
+
+
 def fp8_update_scales(amax: torch.Tensor, scale: torch.Tensor, inv_scale: torch.Tensor, margin: float = 1.0) -> None:
     """delayed scaling: scale = 448 / (amax * margin) for every slot that saw data, inv_scale = 1 / scale, amax = 0"""
     N.check(N.lib().theia_fp8_update_scales(amax.data_ptr(), scale.data_ptr(), inv_scale.data_ptr(), amax.numel(), margin, N.stream_ptr()),
