@@ -239,6 +239,15 @@ typedef struct {
     int32_t pad_;
 } theia_quant_job_t;
 int64_t theia_quantize_fp8_batch_plan(theia_quant_job_t* jobs_host, int njobs);
+/* v11: quantisation fused into the producer.  The *_q8 forms of the HBM-bound passes below ALSO write their main output (y, dx, dpred) as
+ * e4m3 with the slot's delayed scale and record max |value| -- the value as rounded to bf16, i.e. exactly what a theia_quantize_fp8 pass
+ * over the bf16 output would produce: one extra byte per element written instead of a 3-byte-per-element pass.  q8 == NULL (or q8->out ==
+ * NULL): the plain function.  bf16 only. */
+typedef struct {
+    uint8_t* out;       /* e4m3, same shape / pitch (in elements) as the bf16 output */
+    const float* scale; /* device scalar */
+    float* amax;        /* device scalar (atomic max), or NULL */
+} theia_q8_out_t;
 int theia_quantize_fp8_batch(const theia_quant_job_t* jobs_device, int njobs, int64_t total_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -311,11 +320,16 @@ int theia_write_tokens(const float* tok, const float* pos, void* h, int b, int n
  * ---------------------------------------------------------------------------------------------- */
 int theia_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                         float* rstd, int64_t M, int D, float eps, int dtype, void* stream);
+int theia_layernorm_fwd_q8(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t M, int D,
+                           float eps, int dtype, const theia_q8_out_t* q8, void* stream);
 /* dx = LNbwd(dy) (+ dresid if non-NULL);  dgamma/dbeta (f32 [D]) (+)= reduction over rows.
  * workspace: theia_layernorm_bwd_workspace_bytes(M, D) */
 int theia_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         const void* dresid, void* dx, float* dgamma, float* dbeta, float* workspace,
                         int64_t M, int D, int accumulate, int dtype, void* stream);
+int theia_layernorm_bwd_q8(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dresid,
+                           void* dx, float* dgamma, float* dbeta, float* workspace, int64_t M, int D, int accumulate, int dtype,
+                           const theia_q8_out_t* q8, void* stream);
 size_t theia_layernorm_bwd_workspace_bytes(int64_t M, int D);
 
 /* ------------------------------------------------------------------------------------------------
@@ -330,6 +344,8 @@ int theia_layernorm_chw_fwd(const void* x, const float* gamma, const float* beta
  * 4 B/element in bf16 instead of 6; writes stats (mean, rstd) for the backward pass */
 int theia_layernorm_chw_fwd_sums(const void* x, const float* gamma, const float* beta, void* y, const float* sums, float* stats,
                                  int b, int64_t E, float eps, int dtype, void* stream);
+int theia_layernorm_chw_fwd_sums_q8(const void* x, const float* gamma, const float* beta, void* y, const float* sums, float* stats, int b,
+                                    int64_t E, float eps, int dtype, const theia_q8_out_t* q8, void* stream);
 /* dx = LNbwd(dy) * (relu_mask ? (x > 0) : 1): the optional mask folds the backward of the ReLU that produced x.
  * dgamma/dbeta f32 [E] (+)= sum over the batch of dy*xhat / dy. */
 int theia_layernorm_chw_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
@@ -341,6 +357,9 @@ int theia_layernorm_chw_bwd(const void* dy, const void* x, const float* gamma, c
 int theia_layernorm_chw_bwd_colsum(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
                                    float* dgamma, float* dbeta, float* workspace, int b, int64_t E, int relu_mask,
                                    int accumulate, float* dxsum, int C, int dxsum_accumulate, int dtype, void* stream);
+int theia_layernorm_chw_bwd_colsum_q8(const void* dy, const void* x, const float* gamma, const float* stats, void* dx, float* dgamma,
+                                      float* dbeta, float* workspace, int b, int64_t E, int relu_mask, int accumulate, float* dxsum, int C,
+                                      int dxsum_accumulate, int dtype, const theia_q8_out_t* q8, void* stream);
 size_t theia_layernorm_chw_workspace_bytes(int b, int64_t E);
 
 /* ------------------------------------------------------------------------------------------------
@@ -372,6 +391,8 @@ int theia_distill_loss_fwd_t(const void* pred, const void* target, int target_dt
                              int b, int64_t E, int dtype, void* stream);
 int theia_distill_loss_bwd_t(const void* pred, const void* target, int target_dtype, const float* coef, const float* w, void* dpred,
                              int b, int64_t E, int dtype, void* stream);
+int theia_distill_loss_bwd_q8(const void* pred, const void* target, int target_dtype, const float* coef, const float* w, void* dpred,
+                              int b, int64_t E, int dtype, const theia_q8_out_t* q8, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K15: token selection / pooling (models/utils.py:31-43).  x: [b, n, D]; mode 0: x[:, 1:n-disc] -> [b, n-1-disc, D];

@@ -63,6 +63,10 @@ class CastJob(C.Structure):
     ]
 
 
+class Q8Out(C.Structure):  # theia_q8_out_t
+    _fields_ = [("out", C.c_void_p), ("scale", C.c_void_p), ("amax", C.c_void_p)]
+
+
 class QuantJob(C.Structure):  # theia_quant_job_t
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("scale", C.c_void_p), ("amax", C.c_void_p), ("n", C.c_int64),
                 ("first_block", C.c_int32), ("pad_", C.c_int32)]
@@ -104,6 +108,12 @@ _SIGNATURES = {
     "theia_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "theia_quantize_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "theia_fp8_update_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "theia_layernorm_fwd_q8": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_float, C.c_int, C.POINTER(Q8Out), C.c_void_p]),
+    "theia_layernorm_bwd_q8": (C.c_int, [C.c_void_p] * 10 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(Q8Out), C.c_void_p]),
+    "theia_layernorm_chw_fwd_sums_q8": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int64, C.c_float, C.c_int, C.POINTER(Q8Out), C.c_void_p]),
+    "theia_layernorm_chw_bwd_colsum_q8": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                   C.POINTER(Q8Out), C.c_void_p]),
+    "theia_distill_loss_bwd_q8": (C.c_int, [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int64, C.c_int, C.POINTER(Q8Out), C.c_void_p]),
     "theia_quantize_fp8_batch_plan": (C.c_int64, [C.c_void_p, C.c_int]),
     "theia_quantize_fp8_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "theia_colsum_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),

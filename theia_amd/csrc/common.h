@@ -113,6 +113,56 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return s;
 }
 
+// ----------------------------------------------------------------------------------
+// e4m3 copy of a pass's main output (theia_q8_out_t, the *_q8 entry points): 8 values at element offset `off`, quantised from their
+// bf16-rounded form with the slot's scale; `am` collects max |value| (NaN -> +Inf, as theia_quantize_fp8 does)
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ void q8_store8(uint8_t* __restrict__ out, int64_t off, const float (&v)[8], float sc, float& am) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float r = bf16_to_f32(f32_to_bf16(v[j]));
+        const bool nan = r != r;
+        am = nan ? INFINITY : fmaxf(am, fabsf(r));
+        x[j] = nan ? r : fminf(fmaxf(r * sc, -448.f), 448.f);
+    }
+    uint32_t lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(x[4], x[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(x[6], x[7], hi, true);
+    *reinterpret_cast<uint2*>(out + off) = make_uint2(lo, hi);
+}
+// one wave's maximum into the slot.  Device-scope atomics are performed at the memory side and serialise per address (~11 ns each):
+// the atomic is issued only when the wave's maximum exceeds what the slot already holds (an agent-scope load: not a stale line of this
+// XCD's L2), which after the first few waves of a launch is almost never
+__device__ __forceinline__ void q8_flush_wave(float* amax, float am) {
+    if (amax == nullptr) return;  // (uniform: the engine's fused passes run without a maximum, see engine.Fp8Scales.fused)
+    am = wave_max(am);
+    if ((threadIdx.x & 63) == 0) {
+        const float cur = __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(am <= cur)) atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(am));  // non-negative floats order like their bits
+    }
+}
+
+// The *_q8 entry points arm this for the plain entry point they forward to (same thread, next launch); the plain one takes it.
+static thread_local theia_q8_out_t g_q8_armed = {nullptr, nullptr, nullptr};
+static theia_q8_out_t q8_take() {
+    const theia_q8_out_t q = g_q8_armed;
+    g_q8_armed = {nullptr, nullptr, nullptr};
+    return q;
+}
+#define Q8_FORWARD(who, dtype, q8, CALL)                                                                        \
+    do {                                                                                                        \
+        if ((q8) != nullptr && (q8)->out != nullptr) {                                                          \
+            THEIA_CHECK_ARG((dtype) == THEIA_BF16 && (q8)->scale != nullptr, who ": e4m3 output: bf16 passes, with a scale"); \
+            g_q8_armed = *(q8);                                                                                 \
+        }                                                                                                       \
+        const int rc_ = (CALL);                                                                                 \
+        g_q8_armed = {nullptr, nullptr, nullptr};                                                               \
+        return rc_;                                                                                             \
+    } while (0)
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));

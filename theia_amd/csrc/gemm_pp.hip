@@ -771,7 +771,8 @@ static int pp_launch_one(const theia_gemm_args_t* a, hipStream_t stream) {
 int theia_gemm_nt_pp_bm(const theia_gemm_args_t* a, int dtype) {
     if (a->tile == 320256) return 320;
     if (a->tile == 256256) return 256;
-    if (dtype != THEIA_BF16) return 256;
+    if (dtype != THEIA_BF16 && dtype != THEIA_FP8) return 256;
+    if (dtype == THEIA_FP8 && (a->ln_sums != nullptr || a->map.ntaps > 1)) return 256;  // (fp8: 320-row tiles for the plain matrices only)
     if (a->ln_sums != nullptr && a->map.rows_h * a->map.rows_w < 160) return 256;
     static int force = -1;
     if (force < 0) {
@@ -796,7 +797,11 @@ int theia_gemm_nt_pp_launch(const theia_gemm_args_t* a, int dtype, hipStream_t s
     return pp_launch_one<PP_ONE>(a, stream);
 #else
 #ifndef PP_QUICK  // -DPP_QUICK: only the two bf16 single-tap instantiations
-    if (dtype == THEIA_FP8) return sums ? pp_launch_one<fp8_t, 256, true, true>(a, stream) : pp_launch_one<fp8_t, 256, true, false>(a, stream);
+    if (dtype == THEIA_FP8) {  // (round 6: the single-tap instantiation -- clamped rows, no zero page, no per-tap state -- for the plain matrices)
+        if (sums) return pp_launch_one<fp8_t, 256, true, true>(a, stream);
+        if (taps) return pp_launch_one<fp8_t, 256, true, false>(a, stream);
+        return theia_gemm_nt_pp_bm(a, dtype) == 320 ? pp_launch_one<fp8_t, 320, false, false>(a, stream) : pp_launch_one<fp8_t, 256, false, false>(a, stream);
+    }
     if (dtype == THEIA_F32) return sums ? pp_launch_one<float, 256, true, true>(a, stream) : pp_launch_one<float, 256, true, false>(a, stream);
 #endif
     const int bm = theia_gemm_nt_pp_bm(a, dtype);

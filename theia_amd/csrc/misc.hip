@@ -915,22 +915,28 @@ extern "C" int theia_distill_loss_fwd(const void* pred, const float* target, flo
 template <typename T, typename TQ = float>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pred, const TQ* __restrict__ target,
                                                        const float* __restrict__ coef, const float* __restrict__ w,
-                                                       T* __restrict__ dpred, int b, int64_t E) {
+                                                       T* __restrict__ dpred, int b, int64_t E, const theia_q8_out_t q8) {
+    // blockIdx.y = sample; the blocks of a sample stride over its E elements (at most 32 blocks per sample: the e4m3 path ends with one
+    // conditional atomic per wave, see q8_flush_wave)
     const int sample = blockIdx.y;
-    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    if (e >= E) return;
     const float inv_n = 1.0f / ((float)b * (float)E);
     const float wm = w[0] * 2.0f * inv_n, wc = w[1], wl = w[2] * inv_n;
     const float alpha = wc * coef[2 * sample], beta = wc * coef[2 * sample + 1];
-    float p[8], q[8], o[8];
-    load8(pred + (int64_t)sample * E + e, p);
-    load8(target + (int64_t)sample * E + e, q);
+    const float qsc = q8.out != nullptr ? *q8.scale : 0.f;
+    float qam = 0.f;
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; e < E; e += (int64_t)gridDim.x * 256 * 8) {
+        float p[8], q[8], o[8];
+        load8(pred + (int64_t)sample * E + e, p);
+        load8(target + (int64_t)sample * E + e, q);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float d = p[j] - q[j];
-        o[j] = wm * d + wl * fminf(fmaxf(d, -1.0f), 1.0f) + beta * p[j] - alpha * q[j];
+        for (int j = 0; j < 8; ++j) {
+            const float d = p[j] - q[j];
+            o[j] = wm * d + wl * fminf(fmaxf(d, -1.0f), 1.0f) + beta * p[j] - alpha * q[j];
+        }
+        store8(dpred + (int64_t)sample * E + e, o);
+        if (q8.out != nullptr) q8_store8(q8.out, (int64_t)sample * E + e, o, qsc, qam);
     }
-    store8(dpred + (int64_t)sample * E + e, o);
+    if (q8.out != nullptr) q8_flush_wave(q8.amax, qam);
 }
 extern "C" int theia_distill_loss_bwd_t(const void* pred, const void* target, int target_dtype, const float* coef, const float* w, void* dpred,
                                         int b, int64_t E, int dtype, void* stream) {
@@ -938,18 +944,24 @@ extern "C" int theia_distill_loss_bwd_t(const void* pred, const void* target, in
     THEIA_CHECK_ARG(target_dtype == THEIA_F32 || (target_dtype == THEIA_BF16 && dtype == THEIA_BF16),
                     "theia_distill_loss_bwd: targets are f32, or bf16 beside bf16 predictions (target_dtype %d, dtype %d)", target_dtype, dtype);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)((E / 8 + 255) / 256), b);
+    const theia_q8_out_t q8 = q8_take();
+    const int64_t bx = (E / 8 + 255) / 256;
+    const dim3 grid((unsigned)(bx < 32 ? bx : 32), b);
     if (target_dtype == THEIA_BF16) {
-        hipLaunchKernelGGL((loss_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)pred, (const bf16_t*)target, coef, w, (bf16_t*)dpred, b, E);
+        hipLaunchKernelGGL((loss_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)pred, (const bf16_t*)target, coef, w, (bf16_t*)dpred, b, E, q8);
     } else {
-        DISPATCH_T(dtype, hipLaunchKernelGGL((loss_bwd_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const bf16_t*)pred, (const float*)target, coef, w, (bf16_t*)dpred, b, E),
-                   hipLaunchKernelGGL((loss_bwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)pred, (const float*)target, coef, w, (float*)dpred, b, E),
+        DISPATCH_T(dtype, hipLaunchKernelGGL((loss_bwd_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const bf16_t*)pred, (const float*)target, coef, w, (bf16_t*)dpred, b, E, q8),
+                   hipLaunchKernelGGL((loss_bwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)pred, (const float*)target, coef, w, (float*)dpred, b, E, q8),
                    "theia_distill_loss_bwd");
     }
     THEIA_CHECK_LAUNCH("theia_distill_loss_bwd");
     return THEIA_OK;
 }
 
+extern "C" int theia_distill_loss_bwd_q8(const void* pred, const void* target, int target_dtype, const float* coef, const float* w, void* dpred,
+                                         int b, int64_t E, int dtype, const theia_q8_out_t* q8, void* stream) {
+    Q8_FORWARD("theia_distill_loss_bwd_q8", dtype, q8, theia_distill_loss_bwd_t(pred, target, target_dtype, coef, w, dpred, b, E, dtype, stream));
+}
 extern "C" int theia_distill_loss_bwd(const void* pred, const float* target, const float* coef, const float* w, void* dpred,
                                       int b, int64_t E, int dtype, void* stream) {
     return theia_distill_loss_bwd_t(pred, target, THEIA_F32, coef, w, dpred, b, E, dtype, stream);

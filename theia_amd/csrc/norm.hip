@@ -8,14 +8,18 @@
 // ================================================================================================
 constexpr int LN_MAXV = 4;  // 8-element vectors per lane
 
+
+
 // NV = 8-element vectors per lane: 2 for D <= 1024 (the ViT widths), else NV -- the row and, in backward, the per-lane
 // dgamma/dbeta accumulators live in registers, so NV sets the register count (backward: 226 VGPRs at NV = 4).
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_row_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ y,
                                                          float* __restrict__ mean, float* __restrict__ rstd, int64_t M,
-                                                         int D, float eps) {
+                                                         int D, float eps, const theia_q8_out_t q8) {
     const int lane = threadIdx.x & 63;
+    const float qsc = q8.out != nullptr ? *q8.scale : 0.f;
+    float qam = 0.f;
     const int nv = D >> 3;
     const float invD = 1.0f / (float)D;
     // Every load is unconditional, from a vector index clamped into the row (lanes past the row mask their contribution with a select),
@@ -68,12 +72,14 @@ __global__ __launch_bounds__(256) void ln_row_fwd_kernel(const T* __restrict__ x
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * g8[i][j] + b8[i][j];  // (outside the mask: a use under it would pull the loads in)
             if (ok[i]) store8(y + row * D + vc[i] * 8, o);
+            if (q8.out != nullptr && ok[i]) q8_store8(q8.out, row * D + vc[i] * 8, o, qsc, qam);
         }
         if (lane == 0) {
             mean[row] = mu;
             rstd[row] = rs;
         }
     }
+    if (q8.out != nullptr) q8_flush_wave(q8.amax, qam);
 }
 
 extern "C" int theia_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
@@ -82,12 +88,13 @@ extern "C" int theia_layernorm_fwd(const void* x, const float* gamma, const floa
     THEIA_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0 && D <= 8 * 64 * LN_MAXV, "theia_layernorm_fwd: unsupported D=%d", D);
     int blocks = (int)((M + 3) / 4);
     if (blocks > 8192) blocks = 8192;
+    const theia_q8_out_t q8 = q8_take();
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // 8-element vectors per lane: 1 for D <= 512 (DeiT-small / -tiny: a second, fully masked vector would still be loaded -- the loads are
     // unconditional), 2 for D <= 1024, else LN_MAXV
     const int nvl = D <= 512 ? 1 : D <= 1024 ? 2 : LN_MAXV;
 #define LN_FWD_LAUNCH(TT, NVV)                                                                                                            \
-    hipLaunchKernelGGL((ln_row_fwd_kernel<TT, NVV>), dim3(blocks), dim3(256), 0, s, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, M, D, eps)
+    hipLaunchKernelGGL((ln_row_fwd_kernel<TT, NVV>), dim3(blocks), dim3(256), 0, s, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, M, D, eps, q8)
     if (dtype == THEIA_BF16) {
         if (nvl == 1) LN_FWD_LAUNCH(bf16_t, 1); else if (nvl == 2) LN_FWD_LAUNCH(bf16_t, 2); else LN_FWD_LAUNCH(bf16_t, LN_MAXV);
     } else if (dtype == THEIA_F32) {
@@ -99,14 +106,22 @@ extern "C" int theia_layernorm_fwd(const void* x, const float* gamma, const floa
     return THEIA_OK;
 }
 
+extern "C" int theia_layernorm_fwd_q8(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t M,
+                                      int D, float eps, int dtype, const theia_q8_out_t* q8, void* stream) {
+    Q8_FORWARD("theia_layernorm_fwd_q8", dtype, q8, theia_layernorm_fwd(x, gamma, beta, y, mean, rstd, M, D, eps, dtype, stream));
+}
+
 // backward: dx per row (wave); dgamma/dbeta accumulated per lane over the rows this wave visits, then
 // block-reduced through LDS and written as one partial row per block; a second kernel sums the partials.
 template <typename T, int NV, bool HAS_RES>
 __global__ __launch_bounds__(256) void ln_row_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const T* __restrict__ dres,
-                                                         T* __restrict__ dx, float* __restrict__ part, int64_t M, int D) {
+                                                         T* __restrict__ dx, float* __restrict__ part, int64_t M, int D,
+                                                         const theia_q8_out_t q8) {
     extern __shared__ float red[];  // [4][2*D]
+    const float qsc = q8.out != nullptr ? *q8.scale : 0.f;
+    float qam = 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 3;
     const float invD = 1.0f / (float)D;
@@ -162,8 +177,10 @@ __global__ __launch_bounds__(256) void ln_row_bwd_kernel(const T* __restrict__ d
                 for (int j = 0; j < 8; ++j) o[j] += rr[i][j];
             }
             if (ok[i]) store8(dx + row * D + vc[i] * 8, o);
+            if (q8.out != nullptr && ok[i]) q8_store8(q8.out, row * D + vc[i] * 8, o, qsc, qam);
         }
     }
+    if (q8.out != nullptr) q8_flush_wave(q8.amax, qam);
     float* mine = red + wave * 2 * D;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -238,10 +255,11 @@ extern "C" int theia_layernorm_bwd(const void* dy, const void* x, const float* g
     const size_t lds = 4 * 2 * D * sizeof(float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool res = dresid != nullptr;
+    const theia_q8_out_t q8 = q8_take();
     const int nvl = D <= 512 ? 1 : D <= 1024 ? 2 : LN_MAXV;  // (see theia_layernorm_fwd)
 #define LN_BWD_LAUNCH(TT, NVV, RR)                                                                                                      \
     hipLaunchKernelGGL((ln_row_bwd_kernel<TT, NVV, RR>), dim3(blocks), dim3(256), lds, s, (const TT*)dy, (const TT*)x, gamma, mean, rstd, \
-                       (const TT*)dresid, (TT*)dx, workspace, M, D)
+                       (const TT*)dresid, (TT*)dx, workspace, M, D, q8)
 #define LN_BWD_NV(TT, RR)                                                     \
     do {                                                                      \
         if (nvl == 1) LN_BWD_LAUNCH(TT, 1, RR);                               \
@@ -261,6 +279,12 @@ extern "C" int theia_layernorm_bwd(const void* dy, const void* x, const float* g
                        (int64_t)2 * D, dgamma, dbeta, D, accumulate);
     THEIA_CHECK_LAUNCH("theia_layernorm_bwd(reduce)");
     return THEIA_OK;
+}
+extern "C" int theia_layernorm_bwd_q8(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                      const void* dresid, void* dx, float* dgamma, float* dbeta, float* workspace, int64_t M, int D,
+                                      int accumulate, int dtype, const theia_q8_out_t* q8, void* stream) {
+    Q8_FORWARD("theia_layernorm_bwd_q8", dtype, q8,
+               theia_layernorm_bwd(dy, x, gamma, mean, rstd, dresid, dx, dgamma, dbeta, workspace, M, D, accumulate, dtype, stream));
 }
 
 // ================================================================================================
@@ -394,7 +418,9 @@ template <typename T, bool SUMS = false>
 __global__ __launch_bounds__(256) void chw_apply_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ stats,
                                                         T* __restrict__ y, int64_t E, int b, int ngroups, float* __restrict__ stats_out = nullptr,
-                                                        float eps = 0.f) {
+                                                        float eps = 0.f, const theia_q8_out_t q8 = {nullptr, nullptr, nullptr}) {
+    const float qsc = q8.out != nullptr ? *q8.scale : 0.f;
+    float qam = 0.f;
     // a block owns 2048 elements of the affine row (f32 gamma / beta: 8 B per element, in registers) and walks over its group of
     // samples -- the round-2 kernel (one block per sample) re-read those 8 B for every 2 B of x
     const int grp = blockIdx.y;
@@ -430,7 +456,9 @@ __global__ __launch_bounds__(256) void chw_apply_kernel(const T* __restrict__ x,
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (xv[j] - mu) * rs * g8[j] + b8[j];
         store8(y + (int64_t)sample * E + e, o);
+        if (q8.out != nullptr) q8_store8(q8.out, (int64_t)sample * E + e, o, qsc, qam);
     }
+    if (q8.out != nullptr) q8_flush_wave(q8.amax, qam);
 }
 
 extern "C" int theia_layernorm_chw_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
@@ -463,16 +491,22 @@ extern "C" int theia_layernorm_chw_fwd_sums(const void* x, const float* gamma, c
     THEIA_CHECK_ARG(x && gamma && beta && y && sums && stats, "theia_layernorm_chw_fwd_sums: null pointer");
     THEIA_CHECK_ARG(b > 0 && E > 0 && E % 8 == 0, "theia_layernorm_chw_fwd_sums: E=%lld must be a positive multiple of 8", (long long)E);
     THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16, "theia_layernorm_chw_fwd_sums: bad dtype");
+    const theia_q8_out_t q8 = q8_take();
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t colb = (E / 8 + 255) / 256;
     const int ng = chw_sample_groups(b, colb);
     const dim3 grid((unsigned)colb, ng);
     if (dtype == THEIA_BF16)
-        hipLaunchKernelGGL((chw_apply_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, sums, (bf16_t*)y, E, b, ng, stats, eps);
+        hipLaunchKernelGGL((chw_apply_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, sums, (bf16_t*)y, E, b, ng, stats, eps, q8);
     else
         hipLaunchKernelGGL((chw_apply_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, gamma, beta, sums, (float*)y, E, b, ng, stats, eps);
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_fwd_sums");
     return THEIA_OK;
+}
+
+extern "C" int theia_layernorm_chw_fwd_sums_q8(const void* x, const float* gamma, const float* beta, void* y, const float* sums, float* stats,
+                                               int b, int64_t E, float eps, int dtype, const theia_q8_out_t* q8, void* stream) {
+    Q8_FORWARD("theia_layernorm_chw_fwd_sums_q8", dtype, q8, theia_layernorm_chw_fwd_sums(x, gamma, beta, y, sums, stats, b, E, eps, dtype, stream));
 }
 
 // dx for a group of samples + partial affine gradients of that group
@@ -483,46 +517,57 @@ __global__ __launch_bounds__(256) void chw_bwd_kernel(const T* __restrict__ dy, 
                                                       const float* __restrict__ gamma, const float* __restrict__ stats,
                                                       const float* __restrict__ dstat, T* __restrict__ dx,
                                                       float* __restrict__ part, float* __restrict__ part3, int b, int64_t E, int ngroups,
-                                                      int relu_mask) {
+                                                      int relu_mask, const theia_q8_out_t q8) {
     const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    if (e >= E) return;
-    const int grp = blockIdx.y;
-    const int per = (b + ngroups - 1) / ngroups;
-    const int s0 = grp * per, s1 = min(b, s0 + per);
-    float g8[8], ag[8], ab[8], ac[8];
-    load8(gamma + e, g8);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ag[j] = ab[j] = ac[j] = 0.f;
-    for (int s = s0; s < s1; ++s) {
-        const float mu = stats[2 * s], rs = stats[2 * s + 1];
-        const float m1 = dstat[2 * s], m2 = dstat[2 * s + 1];
-        float xv[8], dv[8], o[8];
-        load8(x + (int64_t)s * E + e, xv);
-        load8(dy + (int64_t)s * E + e, dv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xh = (xv[j] - mu) * rs;
-            ag[j] += dv[j] * xh;
-            ab[j] += dv[j];
-            float d = rs * (dv[j] * g8[j] - m1 - xh * m2);
-            if (relu_mask && !(xv[j] > 0.f)) d = 0.f;
-            o[j] = d;
+    const float qsc = q8.out != nullptr ? *q8.scale : 0.f;
+    float qam = 0.f;
+    if (e < E) {  // (no early return: every lane of the wave reaches the reduction of the maxima below)
+        const int grp = blockIdx.y;
+        const int per = (b + ngroups - 1) / ngroups;
+        const int s0 = grp * per, s1 = min(b, s0 + per);
+        float g8[8], ag[8], ab[8], ac[8];
+        load8(gamma + e, g8);
+    #pragma unroll
+        for (int j = 0; j < 8; ++j) ag[j] = ab[j] = ac[j] = 0.f;
+        for (int s = s0; s < s1; ++s) {
+            const float mu = stats[2 * s], rs = stats[2 * s + 1];
+            const float m1 = dstat[2 * s], m2 = dstat[2 * s + 1];
+            float xv[8], dv[8], o[8];
+            load8(x + (int64_t)s * E + e, xv);
+            load8(dy + (int64_t)s * E + e, dv);
+    #pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (xv[j] - mu) * rs;
+                ag[j] += dv[j] * xh;
+                ab[j] += dv[j];
+                float d = rs * (dv[j] * g8[j] - m1 - xh * m2);
+                if (relu_mask && !(xv[j] > 0.f)) d = 0.f;
+                o[j] = d;
+            }
+            store8(dx + (int64_t)s * E + e, o);
+            if (q8.out != nullptr) q8_store8(q8.out, (int64_t)s * E + e, o, qsc, qam);
+            if constexpr (DXSUM) {
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) ac[j] += sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(o[j])) : o[j];  // the value as stored
+            }
         }
-        store8(dx + (int64_t)s * E + e, o);
-        if constexpr (DXSUM) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ac[j] += sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(o[j])) : o[j];  // the value as stored
-        }
+        float* pg = part + (int64_t)grp * 2 * E;
+        store8(pg + e, ag);
+        store8(pg + E + e, ab);
+        if constexpr (DXSUM) store8(part3 + (int64_t)grp * E + e, ac);
     }
-    float* pg = part + (int64_t)grp * 2 * E;
-    store8(pg + e, ag);
-    store8(pg + E + e, ab);
-    if constexpr (DXSUM) store8(part3 + (int64_t)grp * E + e, ac);
+    if (q8.out != nullptr) q8_flush_wave(q8.amax, qam);
 }
 
 extern "C" int theia_layernorm_chw_bwd_colsum(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
                                               float* dgamma, float* dbeta, float* workspace, int b, int64_t E, int relu_mask,
                                               int accumulate, float* dxsum, int C, int dxsum_accumulate, int dtype, void* stream);
+extern "C" int theia_layernorm_chw_bwd_colsum_q8(const void* dy, const void* x, const float* gamma, const float* stats, void* dx, float* dgamma,
+                                                 float* dbeta, float* workspace, int b, int64_t E, int relu_mask, int accumulate, float* dxsum,
+                                                 int C, int dxsum_accumulate, int dtype, const theia_q8_out_t* q8, void* stream) {
+    Q8_FORWARD("theia_layernorm_chw_bwd_colsum_q8", dtype, q8,
+               theia_layernorm_chw_bwd_colsum(dy, x, gamma, stats, dx, dgamma, dbeta, workspace, b, E, relu_mask, accumulate, dxsum, C, dxsum_accumulate, dtype, stream));
+}
 extern "C" int theia_layernorm_chw_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
                                        float* dgamma, float* dbeta, float* workspace, int b, int64_t E, int relu_mask,
                                        int accumulate, int dtype, void* stream) {
@@ -537,6 +582,7 @@ extern "C" int theia_layernorm_chw_bwd_colsum(const void* dy, const void* x, con
     THEIA_CHECK_ARG(dtype == THEIA_F32 || dtype == THEIA_BF16, "theia_layernorm_chw_bwd: bad dtype");
     const int nch = chw_chunks(E);
     const int ng = chw_groups(b, E);
+    const theia_q8_out_t q8 = q8_take();
     // workspace layout (see theia_layernorm_chw_workspace_bytes): [partial stats | dstat | affine partials]
     float* part_stats = workspace;
     float* dstat = part_stats + (((size_t)b * nch * 2 + 63) / 64) * 64;
@@ -554,11 +600,11 @@ extern "C" int theia_layernorm_chw_bwd_colsum(const void* dy, const void* x, con
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_bwd(finalize)");
     const dim3 grid((unsigned)((E / 8 + 255) / 256), ng);
     if (dtype == THEIA_BF16) {
-        if (dxsum) hipLaunchKernelGGL((chw_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, stats, dstat, (bf16_t*)dx, parts, parts3, b, E, ng, relu_mask);
-        else hipLaunchKernelGGL((chw_bwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, stats, dstat, (bf16_t*)dx, parts, parts3, b, E, ng, relu_mask);
+        if (dxsum) hipLaunchKernelGGL((chw_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, stats, dstat, (bf16_t*)dx, parts, parts3, b, E, ng, relu_mask, q8);
+        else hipLaunchKernelGGL((chw_bwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, stats, dstat, (bf16_t*)dx, parts, parts3, b, E, ng, relu_mask, q8);
     } else {
-        if (dxsum) hipLaunchKernelGGL((chw_bwd_kernel<float, true>), grid, dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, stats, dstat, (float*)dx, parts, parts3, b, E, ng, relu_mask);
-        else hipLaunchKernelGGL((chw_bwd_kernel<float, false>), grid, dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, stats, dstat, (float*)dx, parts, parts3, b, E, ng, relu_mask);
+        if (dxsum) hipLaunchKernelGGL((chw_bwd_kernel<float, true>), grid, dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, stats, dstat, (float*)dx, parts, parts3, b, E, ng, relu_mask, q8);
+        else hipLaunchKernelGGL((chw_bwd_kernel<float, false>), grid, dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, stats, dstat, (float*)dx, parts, parts3, b, E, ng, relu_mask, q8);
     }
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_bwd(dx)");
     if (dxsum) {  // [ng * H*W][C] f32 -> [C]

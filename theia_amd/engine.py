@@ -129,6 +129,8 @@ class Fp8Scales:
         self.inv = torch.ones(capacity, dtype=torch.float32, device=device)
         self.index: Dict[str, int] = {}
         self.calibrated: set = set()
+        self.steps = 0                                                          # update() calls so far
+        self.refresh = max(1, int(os.environ.get("THEIA_FP8_AMAX_EVERY", "16")))  # every refresh-th step records maxima (see fused())
 
     def slot(self, site: str) -> int:
         i = self.index.get(site)
@@ -147,12 +149,28 @@ class Fp8Scales:
             ops.fp8_update_scales(am, sc, inv)
             self.calibrated.add(site)
             return ops.quantize_fp8(x2d, sc, am, out=q), inv
-        return ops.quantize_fp8(x2d, sc, am), inv
+        # (between refresh steps the pass does not record the maximum either: its one atomic per block is ~10 us of a 12-50 us pass)
+        return ops.quantize_fp8(x2d, sc, am if self.steps % self.refresh == 0 else None), inv
+
+    def fused(self, site: str, like: torch.Tensor):
+        """(e4m3 buffer shaped like `like`, scale, amax, inv_scale) for a producer that writes its output's e4m3 copy itself (the *_q8
+        passes: ops.layernorm_fwd(..., q8=) ...), or None while the site has not calibrated itself through quantize() yet (its first
+        step) -- round 6: the separate 3-byte-per-element pass becomes one more byte written by the pass that produces the tensor"""
+        # The fused passes do NOT record max|x|: a maximum per slot is one device-scope atomic per wave or block, performed at the memory side
+        # and serialised per address (the effect that made the stand-alone pass take 90-105 us, above) -- with them the fused LayerNorm passes
+        # were 0.4 ms per step SLOWER than the separate quantise passes.  Instead every `refresh`-th step runs the separate passes (which
+        # record the maxima and so refresh the scales); in between the scales stay as they are -- delayed scaling with an update interval,
+        # e4m3 saturation (+-448) under it as always.  THEIA_FP8_AMAX_EVERY (default 16).
+        if site not in self.calibrated or self.steps % self.refresh == 0:
+            return None
+        i = self.slot(site)
+        return (torch.empty(like.shape, dtype=torch.float8_e4m3fn, device=like.device), self.scale[i:i + 1], None, self.inv[i:i + 1])
 
     def update(self, activations_only: bool = False) -> None:
         """amax -> next scale / inverse scale.  activations_only: leave the weight ("w:") slots alone -- their e4m3 copies in the
         operand cache were quantised with the scale in force when the cache was built and carry a VIEW of this `inv`; refreshing a
         weight slot without re-quantising the weight would rescale every output of that GEMM by amax_t / amax_{t-1}."""
+        self.steps += 1
         n = len(self.index)
         if not n:
             return
@@ -490,10 +508,28 @@ class StudentEngine:
         self._opkey = key
         return self._opcache
 
-    def _mm(self, x: torch.Tensor, key: str, bias: Optional[torch.Tensor] = None, **epi) -> torch.Tensor:
+    def _q8_conv(self, wkey: str, like: torch.Tensor, kind: str):
+        """_q8_for for the input of a convolution: only the kinds that never run on the bf16 3x3 kernel (the stride-2 transposed convolutions
+        and the stride-1 pad's data-gradient), and inside the row range _conv_operands quantises"""
+        if kind not in ("up31", "up64", "pad_d") or like.numel() // self.D >= (1 << 22):
+            return None
+        return self._q8_for(wkey, like)
+
+    def _q8_for(self, key: str, like: torch.Tensor):
+        """the e4m3 side output a producer should write for the GEMM input of operand `key` (fp8 mode, site calibrated), else None"""
+        if self.fp8 is None or key + ".f8" not in self._opcache or like.dtype != torch.bfloat16 or not like.is_contiguous():
+            return None
+        if os.environ.get("THEIA_FP8_FUSED_QUANT", "1") == "0":  # A/B switch: every GEMM input through its own quantise pass
+            return None
+        return self.fp8.fused("x:" + key, like)
+
+    def _mm(self, x: torch.Tensor, key: str, bias: Optional[torch.Tensor] = None, x8=None, **epi) -> torch.Tensor:
         """x [M, K] @ operand `key`^T with the epilogue `epi`: fp8 operands when the engine runs in fp8 mode and the operand has an
-        e4m3 copy (K a multiple of 64, N >= 64), bf16 / f32 otherwise."""
+        e4m3 copy (K a multiple of 64, N >= 64), bf16 / f32 otherwise.  x8: what _q8_for(key, x) returned when x's producer already
+        wrote the e4m3 copy."""
         oc = self._opcache
+        if x8 is not None and "out" not in epi:
+            return ops.linear(x8[0].view(x.shape), oc[key + ".f8"], bias, scale_inv=(x8[3], oc[key + ".inv"]), **epi)
         # (the fp8 operands exist for the persistent kernel only, which addresses M < 2^24 rows: beyond that -- a head's 64x64 maps at
         # b >= 4096 per GPU -- the launch keeps its bf16 operands instead of failing in the middle of a step)
         if self.fp8 is not None and key + ".f8" in oc and "out" not in epi and x.shape[0] < (1 << 24):
@@ -639,13 +675,15 @@ class StudentEngine:
             ops.write_tokens(emb.reg_token.view(geo.nreg, D), emb.reg_pos_embed.view(geo.nreg, D), h, b, NTOK, geo.tok0 + P, geo.nreg, D)
         saved: Dict[str, Any] = {"b": b, "geo": geo, "patches": patches if save else None, "layers": []}
         for i, L in enumerate(vit.layers):
-            a, mean1, rstd1 = ops.layernorm_fwd(h, L.layernorm_before.weight, L.layernorm_before.bias, LN_EPS_VIT)
-            qkv = self._mm(a, f"l{i}.wqkv", oc[f"l{i}.bqkv"])
+            q8a = self._q8_for(f"l{i}.wqkv", h)
+            a, mean1, rstd1 = ops.layernorm_fwd(h, L.layernorm_before.weight, L.layernorm_before.bias, LN_EPS_VIT, q8=q8a[:3] if q8a is not None else None)
+            qkv = self._mm(a, f"l{i}.wqkv", oc[f"l{i}.bqkv"], x8=q8a)
             o, lse = ops.attention_fwd(qkv, b, NTOK, nh)
             h1 = self._mm(o, f"l{i}.wo", L.attention.o_proj.bias, resid=h)
-            m, mean2, rstd2 = ops.layernorm_fwd(h1, L.layernorm_after.weight, L.layernorm_after.bias, LN_EPS_VIT)
+            q8m = self._q8_for(f"l{i}.w1", h1)
+            m, mean2, rstd2 = ops.layernorm_fwd(h1, L.layernorm_after.weight, L.layernorm_after.bias, LN_EPS_VIT, q8=q8m[:3] if q8m is not None else None)
             pre = torch.empty(M, F, dtype=T, device=dev) if save else None
-            act = self._mm(m, f"l{i}.w1", L.mlp.fc1.bias, act=N.ACT_GELU, aux_out=pre)
+            act = self._mm(m, f"l{i}.w1", L.mlp.fc1.bias, x8=q8m, act=N.ACT_GELU, aux_out=pre)
             h2 = self._mm(act, f"l{i}.w2", L.mlp.fc2.bias, resid=h1)
             if save:
                 saved["layers"].append((h, mean1, rstd1, a, qkv, o, lse, h1, mean2, rstd2, m, pre, act))
@@ -702,7 +740,8 @@ class StudentEngine:
                 wgrad(dy, x, lin.weight, lin.bias)
 
         hL, meanf, rstdf = saved["final"]
-        dh = self._ln_bwd(dz, hL, vit.layernorm, meanf, rstdf, None, ws)
+        q8dh = self._q8_for(f"l{NUM_LAYERS - 1}.w2T", dz)  # (fp8 mode: the LayerNorm backward passes write the e4m3 copy their consumer GEMM reads)
+        dh = self._ln_bwd(dz, hL, vit.layernorm, meanf, rstdf, None, ws, q8=q8dh)
         vit_buckets = [bk for bk in self.buckets if bk.name.startswith("vit:")]  # layer groups 9-11, 6-8, 3-5, then 2, 1, 0 (+ embeddings)
         group_lo = {int(bk.name[4:].split("-")[0]): bk for bk in vit_buckets[:-1]}  # lowest layer of a group -> its bucket
         for i in range(NUM_LAYERS - 1, -1, -1):
@@ -711,16 +750,17 @@ class StudentEngine:
             saved["layers"][i] = None
             # h2 = h1 + fc2(act)
             wgrad_later(dh, act, L.mlp.fc2)
-            dpre = self._mm(dh, f"l{i}.w2T", None, act=N.ACT_MUL_DGELU, aux_in=pre)
+            dpre = self._mm(dh, f"l{i}.w2T", None, x8=q8dh, act=N.ACT_MUL_DGELU, aux_in=pre)
             del act, pre
             wgrad_later(dpre, m, L.mlp.fc1)
             dm = self._mm(dpre, f"l{i}.w1T")
             del dpre
-            dh1 = self._ln_bwd(dm, h1, L.layernorm_after, mean2, rstd2, dh, ws)
+            q8dh1 = self._q8_for(f"l{i}.woT", dm)
+            dh1 = self._ln_bwd(dm, h1, L.layernorm_after, mean2, rstd2, dh, ws, q8=q8dh1)
             del dm, dh
             # h1 = h + o_proj(o).  Its weight gradient ([D, D]: 9 output tiles, i.e. 28 M-splits alone) waits for the q/k/v gradient and
             # shares that launch (36 tiles x 7 splits; ops.linear_wgrad_group); alone only when the fused q/k/v path is not taken
-            do = self._mm(dh1, f"l{i}.woT")
+            do = self._mm(dh1, f"l{i}.woT", x8=q8dh1)
             dqkv = ops.attention_bwd(qkv, o, do, lse, b, NTOK, nh, ws)
             del do
             qkv_mods = (L.attention.q_proj, L.attention.k_proj, L.attention.v_proj)
@@ -734,7 +774,8 @@ class StudentEngine:
                     wgrad(sl, a, prj.weight, prj.bias)
             da = self._mm(dqkv, f"l{i}.wqkvT")
             del dqkv
-            dh = self._ln_bwd(da, h, L.layernorm_before, mean1, rstd1, dh1, ws)
+            q8dh = self._q8_for(f"l{i - 1}.w2T", da) if i > 0 else None
+            dh = self._ln_bwd(da, h, L.layernorm_before, mean1, rstd1, dh1, ws, q8=q8dh)
             del da, dh1
             if i in group_lo:
                 self._bucket_done(group_lo[i], side)
@@ -784,7 +825,7 @@ class StudentEngine:
         ops.wgrad_finish(slabs, splits, D, 1, 768, gpw, 768, 0, 1, acc)
         self._bucket_done(vit_buckets[-1], side)
 
-    def _ln_bwd(self, dy, x, ln, mean, rstd, dresid, ws):
+    def _ln_bwd(self, dy, x, ln, mean, rstd, dresid, ws, q8=None):
         """row-LayerNorm backward with the affine gradients written to the bucket.  The kernel takes ONE accumulate flag for weight and
         bias; when the two parameters disagree (one frozen, or only one of the .grad tensors reset to None under gradient
         accumulation) the slot that must NOT accumulate is zeroed first and the kernel accumulates into both."""
@@ -793,7 +834,7 @@ class StudentEngine:
         if accw != accb:
             ops.fill_zero(gw if not accw else gb)
             accw = accb = True
-        return ops.layernorm_bwd(dy, x, ln.weight, mean, rstd, dresid, gw, gb, accw, ws)
+        return ops.layernorm_bwd(dy, x, ln.weight, mean, rstd, dresid, gw, gb, accw, ws, q8=q8[:3] if q8 is not None else None)
 
     def _wgrad_qkv_fused(self, dqkv: torch.Tensor, a: torch.Tensor, mods, side: "_SideQueue", also=None) -> bool:
         """The q / k / v weight and bias gradients as ONE [3D, D] weight-gradient GEMM when their slots in the flat gradient bucket
@@ -870,11 +911,11 @@ class StudentEngine:
         tr = self.rvfm.translator
         return tr.translator_heads[tr.legit_target_model_name_map[t]]
 
-    def _conv_fwd(self, x, wf, bias, plan, b, out, relu: bool, sums: Optional[torch.Tensor] = None):
+    def _conv_fwd(self, x, wf, bias, plan, b, out, relu: bool, sums: Optional[torch.Tensor] = None, x8=None):
         """sums: zeroed f32 [b, 2]; every launch (4 output-parity classes for a stride-2 transposed convolution) adds the per-sample
         (sum, sum of squares) of what it stores: the statistics of the whole-sample LayerNorm that follows."""
         C = self.D
-        wf, scale_inv = self._conv_operands(x, wf, None if len(plan.fwd) > 1 else (plan.fwd[0][0], b * plan.fwd[0][1], out))
+        wf, scale_inv = self._conv_operands(x, wf, None if len(plan.fwd) > 1 else (plan.fwd[0][0], b * plan.fwd[0][1], out), x8=x8)
         if scale_inv is not None:
             x = scale_inv[2]
         for rmap, mpi in plan.fwd:
@@ -882,7 +923,7 @@ class StudentEngine:
                         ln_sums=sums, scale_inv=scale_inv[:2] if scale_inv is not None else None)
         return out
 
-    def _conv_operands(self, x: torch.Tensor, wkey: str, launch=None):
+    def _conv_operands(self, x: torch.Tensor, wkey: str, launch=None, x8=None):
         """(weight operand, None) -- or in fp8 mode (e4m3 weight, (inv_x, inv_w, e4m3 activation)): the activation (any NHWC /
         token layout with C channels innermost) is quantised as a [rows, C] matrix, the row map addresses it unchanged.
         launch = (row map, M, out) of a single-launch convolution: when the bf16 launch would run on the one-image-per-tile 3x3 kernel
@@ -898,6 +939,8 @@ class StudentEngine:
                 keep = self._fp8_conv_bf16[key] = ops.gemm_nt(x, oc[wkey], out, M, C, rmap.ntaps * C, rmap, 9 * C, C, plan_only=True) == 256009
             if keep:
                 return oc[wkey], None
+        if x8 is not None:  # (the producer of x wrote the e4m3 copy: _q8_conv)
+            return oc[wkey + ".f8"], (x8[3], oc[wkey + ".inv"], x8[0].view(-1, self.D))
         if self.fp8 is not None and wkey + ".f8" in oc and x.numel() // self.D < (1 << 22):  # (output rows <= 4x input rows < 2^24: see _mm)
             x8, inv = self.fp8.quantize(x.reshape(-1, self.D), "x:" + wkey)
             return oc[wkey + ".f8"], (inv, oc[wkey + ".inv"], x8)
@@ -927,15 +970,19 @@ class StudentEngine:
             sums = torch.zeros(3, b, 2, dtype=torch.int64, device=dev)  # LayerNorm statistics out of the convolutions' epilogues (fixed point)
             u1 = torch.empty(b, 256 * C, dtype=T, device=dev)
             self._conv_fwd(z, pf + "pad.wf", hm.pad["1"].bias, self._plan("pad"), b, u1, relu=False, sums=sums[0])
-            v1, st0 = ops.layernorm_chw_fwd(u1, oc[pf + "ln0.g"], oc[pf + "ln0.b"], LN_EPS_HEAD, chw_ws, sums=sums[0])
             p1, p4 = ("up31", "up64") if hm.kind == "up64" else ("conv16", "conv16")
+            # (fp8 mode: each LayerNorm apply also writes the e4m3 copy its consumer GEMM reads, where that consumer takes e4m3 operands)
+            q1 = self._q8_conv(pf + "c1.wf", u1, p1)
+            v1, st0 = ops.layernorm_chw_fwd(u1, oc[pf + "ln0.g"], oc[pf + "ln0.b"], LN_EPS_HEAD, chw_ws, sums=sums[0], q8=q1[:3] if q1 else None)
             u2 = torch.empty(b, s1 * s1 * C, dtype=T, device=dev)
-            self._conv_fwd(v1, pf + "c1.wf", hm.adapter["1"].bias, self._plan(p1), b, u2, relu=True, sums=sums[1])
-            v2, st3 = ops.layernorm_chw_fwd(u2, oc[pf + "ln3.g"], oc[pf + "ln3.b"], LN_EPS_HEAD, chw_ws, sums=sums[1])
+            self._conv_fwd(v1, pf + "c1.wf", hm.adapter["1"].bias, self._plan(p1), b, u2, relu=True, sums=sums[1], x8=q1)
+            q2 = self._q8_conv(pf + "c4.wf", u2, p4)
+            v2, st3 = ops.layernorm_chw_fwd(u2, oc[pf + "ln3.g"], oc[pf + "ln3.b"], LN_EPS_HEAD, chw_ws, sums=sums[1], q8=q2[:3] if q2 else None)
             u3 = torch.empty(b, s2 * s2 * C, dtype=T, device=dev)
-            self._conv_fwd(v2, pf + "c4.wf", hm.adapter["4"].bias, self._plan(p4), b, u3, relu=True, sums=sums[2])
-            v3, st6 = ops.layernorm_chw_fwd(u3, oc[pf + "ln6.g"], oc[pf + "ln6.b"], LN_EPS_HEAD, chw_ws, sums=sums[2])
-            pred = self._mm(v3.view(b * s2 * s2, C), pf + "w8", hm.adapter["8"].bias)
+            self._conv_fwd(v2, pf + "c4.wf", hm.adapter["4"].bias, self._plan(p4), b, u3, relu=True, sums=sums[2], x8=q2)
+            q3 = self._q8_for(pf + "w8", u3) if b * s2 * s2 < (1 << 24) else None
+            v3, st6 = ops.layernorm_chw_fwd(u3, oc[pf + "ln6.g"], oc[pf + "ln6.b"], LN_EPS_HEAD, chw_ws, sums=sums[2], q8=q3[:3] if q3 else None)
+            pred = self._mm(v3.view(b * s2 * s2, C), pf + "w8", hm.adapter["8"].bias, x8=q3)
             outs.append(pred.view(b, s2 * s2, -1))
             if save:
                 saved.append((u1, st0, v1, u2, st3, v2, u3, st6, v3))
@@ -1009,14 +1056,15 @@ class StudentEngine:
 
                 side.run(lambda: ops.conv_wgrad(plan, dy2d, x, b, C, gw, accw, side.ws, bias=bias), dy2d, x)
 
-            def ln_bwd(dy, x, stats, idx, hw, relu_mask, bias_of=None):
+            def ln_bwd(dy, x, stats, idx, hw, relu_mask, bias_of=None, q8=None):
                 """bias_of: the convolution that produced x, when its weight-gradient GEMM cannot carry the bias gradient (the stride-2
                 transposed convolutions reduce over input pixels): its bias gradient = the column sums of dx, out of this pass."""
                 E = hw * hw * C
                 tmp_g = ws[chw_need: chw_need + E]
                 tmp_b = ws[chw_need + E3: chw_need + E3 + E]
                 dxsum = self._grad(bias_of.bias) if (train and bias_of is not None) else None
-                dx = ops.layernorm_chw_bwd(dy, x, oc[pf + f"ln{idx}.g"], stats, tmp_g, tmp_b, relu_mask, False, ws[:chw_need], dxsum=dxsum)
+                dx = ops.layernorm_chw_bwd(dy, x, oc[pf + f"ln{idx}.g"], stats, tmp_g, tmp_b, relu_mask, False, ws[:chw_need], dxsum=dxsum,
+                                           q8=q8[:3] if q8 else None)
                 if train:
                     g, acc = self._grad(hm.adapter[idx].weight)
                     ops.transpose_acc(tmp_g, g, hw * hw, C, acc)  # [HW][C] (NHWC reduction order) -> [C][H][W]
@@ -1024,40 +1072,46 @@ class StudentEngine:
                     ops.transpose_acc(tmp_b, g, hw * hw, C, acc)
                 return dx
 
-            def conv_dgrad(dy, wd_key, plan, out, resid=None):
+            def conv_dgrad(dy, wd_key, plan, out, resid=None, x8=None):
                 rmap, mpi = plan.dgrad
-                wd, scale_inv = self._conv_operands(dy, wd_key, (rmap, b * mpi, out))
+                wd, scale_inv = self._conv_operands(dy, wd_key, (rmap, b * mpi, out), x8=x8)
                 ops.gemm_nt(dy if scale_inv is None else scale_inv[2], wd, out, b * mpi, C, 9 * C, rmap, 9 * C, C, resid=resid,
                             scale_inv=scale_inv[:2] if scale_inv is not None else None)
                 return out
 
             p1, p4 = ("up31", "up64") if hm.kind == "up64" else ("conv16", "conv16")
+            q8dp = getattr(dpreds[hi], "_theia_q8", None)
+            q8dp = q8dp[1] if q8dp is not None and q8dp[0] == dp.data_ptr() and q8dp[1][0].numel() == dp.numel() else None
             lin_grads(dp, v3.view(b * s2 * s2, C), hm.adapter["8"])
-            dv3 = self._mm(dp, pf + "w8T")
+            dv3 = self._mm(dp, pf + "w8T", x8=q8dp)
             del v3
             swapped4, swapped1 = self._plan(p4).wgrad_swapped, self._plan(p1).wgrad_swapped
-            du3 = ln_bwd(dv3.view(b, E3), u3, st6, "6", s2, True, bias_of=hm.adapter["4"] if swapped4 else None)
+            q6 = self._q8_conv(pf + "c4.wd", u3, p4)
+            du3 = ln_bwd(dv3.view(b, E3), u3, st6, "6", s2, True, bias_of=hm.adapter["4"] if swapped4 else None, q8=q6)
             del dv3, u3
             conv_grads(du3.view(b * s2 * s2, C), v2, hm.adapter["4"], self._plan(p4), b * s2 * s2, bias_done=swapped4)
-            dv2 = conv_dgrad(du3, pf + "c4.wd", self._plan(p4), torch.empty(b, s1 * s1 * C, dtype=T, device=dev))
+            dv2 = conv_dgrad(du3, pf + "c4.wd", self._plan(p4), torch.empty(b, s1 * s1 * C, dtype=T, device=dev), x8=q6)
             del du3, v2
-            du2 = ln_bwd(dv2, u2, st3, "3", s1, True, bias_of=hm.adapter["1"] if swapped1 else None)
+            q3b = self._q8_conv(pf + "c1.wd", u2, p1)
+            du2 = ln_bwd(dv2, u2, st3, "3", s1, True, bias_of=hm.adapter["1"] if swapped1 else None, q8=q3b)
             del dv2, u2
             conv_grads(du2.view(b * s1 * s1, C), v1, hm.adapter["1"], self._plan(p1), b * s1 * s1, bias_done=swapped1)
-            dv1 = conv_dgrad(du2, pf + "c1.wd", self._plan(p1), torch.empty(b, 256 * C, dtype=T, device=dev))
+            dv1 = conv_dgrad(du2, pf + "c1.wd", self._plan(p1), torch.empty(b, 256 * C, dtype=T, device=dev), x8=q3b)
             del du2, v1
-            du1 = ln_bwd(dv1, u1, st0, "0", s0, False)
+            q0 = self._q8_conv(pf + "pad.wd", u1, "pad_d") if self._fp8_conv_bf16.get((pf + "pad.wd", b * self._plan("pad").dgrad[1])) is False else None
+            du1 = ln_bwd(dv1, u1, st0, "0", s0, False, q8=q0)
             del dv1, u1
             conv_grads(du1.view(b * 256, C), z, hm.pad["1"], self._plan("pad"), b * 256)
-            conv_dgrad(du1, pf + "pad.wd", self._plan("pad"), dz, resid=dz)
+            conv_dgrad(du1, pf + "pad.wd", self._plan("pad"), dz, resid=dz, x8=q0)
             del du1
             if train:
                 self._bucket_done(bucket, side)
         return dz
 
     # ================================================================== loss
-    def distill_loss(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
-        """-> f32[3] = (mse, cos, smooth_l1) of one teacher (models/rvfm.py:153-168)."""
+    def distill_loss(self, pred: torch.Tensor, target: torch.Tensor, head: Optional[str] = None) -> torch.Tensor:
+        """-> f32[3] = (mse, cos, smooth_l1) of one teacher (models/rvfm.py:153-168).  head: the teacher whose translator head produced
+        `pred` (fp8 mode: the gradient pass then also writes the e4m3 copy that head's Linear data-gradient GEMM reads)."""
         # float32 as the reference feeds them (.float() of bf16-normalised features, train_rvfm.py:112-114, data_utils.py:374-379) -- or
         # those same values still in bf16 beside bf16 predictions: identical losses and gradients, 2 bytes less per element and pass
         if target.dtype != torch.float32 and not (target.dtype == torch.bfloat16 and pred.dtype == torch.bfloat16):
@@ -1067,7 +1121,7 @@ class StudentEngine:
             raise ValueError(f"prediction {tuple(pred.shape)} and target {tuple(target.shape)} shapes differ")
         target = target.to(pred.device).contiguous()
         if torch.is_grad_enabled() and pred.requires_grad:
-            return _LossFn.apply(self, pred, target)
+            return _LossFn.apply(self, pred, target, head)
         b = pred.shape[0]
         losses, _ = ops.distill_loss_fwd(pred.contiguous().view(b, -1), target.view(b, -1),
                                          self.ws(N.lib().theia_distill_loss_workspace_bytes(b, pred[0].numel()) // 4, pred.device))
@@ -1105,7 +1159,8 @@ class _TranslatorFn(torch.autograd.Function):
 
 class _LossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng: StudentEngine, pred, target):
+    def forward(ctx, eng: StudentEngine, pred, target, head=None):
+        ctx.eng, ctx.head = eng, head
         b = pred.shape[0]
         p2 = pred.contiguous().view(b, -1)
         t2 = target.view(b, -1)
@@ -1115,5 +1170,9 @@ class _LossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dl):
-        dp = ops.distill_loss_bwd(ctx.p2, ctx.t2, ctx.coef, dl.contiguous().float())
-        return None, dp.view(ctx.shape), None
+        q8 = ctx.eng._q8_for(f"h:{ctx.head}.w8T", ctx.p2) if ctx.head is not None and ctx.p2.shape[0] * (ctx.p2.shape[1] // ctx.shape[-1]) < (1 << 24) else None
+        dp = ops.distill_loss_bwd(ctx.p2, ctx.t2, ctx.coef, dl.contiguous().float(), q8=q8[:3] if q8 else None)
+        out = dp.view(ctx.shape)
+        if q8 is not None:  # travels to _translator_bwd on the gradient tensor itself (checked there against its data pointer)
+            out._theia_q8 = (dp.data_ptr(), q8)
+        return None, out, None, None

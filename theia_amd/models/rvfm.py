@@ -142,7 +142,7 @@ class RobotVisionFM(nn.Module):
         per = []
         names = list(pred_features.keys())
         for t in names:
-            per.append(self._engine.distill_loss(pred_features[t], y[t]))  # f32[3] = (mse, cos, l1)
+            per.append(self._engine.distill_loss(pred_features[t], y[t], head=t))  # f32[3] = (mse, cos, l1)
         allv = torch.stack(per, 0)  # [T, 3]
         avg = allv.sum(0) * (1.0 / T)
         if as_float:

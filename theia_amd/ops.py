@@ -573,39 +573,51 @@ def write_tokens(tok: torch.Tensor, pos: torch.Tensor, h: torch.Tensor, b: int, 
             "theia_write_tokens")
 
 
-def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
+def _q8(q8) -> Optional["N.Q8Out"]:
+    """q8 = (e4m3 tensor shaped like the pass's bf16 output, scale [1] f32, amax [1] f32 or None) -> theia_q8_out_t (or None)"""
+    if q8 is None:
+        return None
+    o = N.Q8Out()
+    o.out, o.scale, o.amax = q8[0].data_ptr(), q8[1].data_ptr(), N.ptr(q8[2])
+    assert q8[0].dtype == torch.float8_e4m3fn and q8[0].is_contiguous()
+    return o
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, q8=None):
+    """q8 (fp8 mode): the pass also writes y as e4m3 (theia_layernorm_fwd_q8) -- see _q8"""
     M, D = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(M, dtype=torch.float32, device=x.device)
     rstd = torch.empty(M, dtype=torch.float32, device=x.device)
-    N.check(N.lib().theia_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
-                                        rstd.data_ptr(), M, D, eps, _dt(x), N.stream_ptr()), "theia_layernorm_fwd")
+    N.check(N.lib().theia_layernorm_fwd_q8(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                           rstd.data_ptr(), M, D, eps, _dt(x), _q8(q8), N.stream_ptr()), "theia_layernorm_fwd")
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dresid, dgamma, dbeta, accumulate: bool, ws: Optional[torch.Tensor] = None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dresid, dgamma, dbeta, accumulate: bool, ws: Optional[torch.Tensor] = None, q8=None):
     M, D = x.shape
     dx = torch.empty_like(x)
     need = N.lib().theia_layernorm_bwd_workspace_bytes(M, D) // 4
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.float32, device=x.device)
-    N.check(N.lib().theia_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                        N.ptr(dresid), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), M, D,
-                                        int(accumulate), _dt(x), N.stream_ptr()), "theia_layernorm_bwd")
+    N.check(N.lib().theia_layernorm_bwd_q8(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                           N.ptr(dresid), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), M, D,
+                                           int(accumulate), _dt(x), _q8(q8), N.stream_ptr()), "theia_layernorm_bwd")
     return dx
 
 
 def layernorm_chw_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, ws: Optional[torch.Tensor] = None,
-                      sums: Optional[torch.Tensor] = None):
+                      sums: Optional[torch.Tensor] = None, q8=None):
     """x [b, E] (NHWC flattened); gamma/beta f32 [E] in NHWC order.  sums: int64 [b, 2] fixed-point per-sample (sum, sum of squares) of x already
     accumulated by the producing GEMM's epilogue (gemm_nt(..., ln_sums=)) -> one pass instead of three."""
     b, E = x.shape
     y = torch.empty_like(x)
     stats = torch.empty(b, 2, dtype=torch.float32, device=x.device)
     if sums is not None:
-        N.check(N.lib().theia_layernorm_chw_fwd_sums(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), sums.data_ptr(),
-                                                     stats.data_ptr(), b, E, eps, _dt(x), N.stream_ptr()), "theia_layernorm_chw_fwd_sums")
+        N.check(N.lib().theia_layernorm_chw_fwd_sums_q8(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), sums.data_ptr(),
+                                                        stats.data_ptr(), b, E, eps, _dt(x), _q8(q8), N.stream_ptr()), "theia_layernorm_chw_fwd_sums")
         return y, stats
+    assert q8 is None, "the e4m3 output exists on the one-pass (sums) form only"
     need = N.lib().theia_layernorm_chw_workspace_bytes(b, E) // 4
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.float32, device=x.device)
@@ -615,7 +627,7 @@ def layernorm_chw_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, 
 
 
 def layernorm_chw_bwd(dy, x, gamma, stats, dgamma, dbeta, relu_mask: bool, accumulate: bool, ws: Optional[torch.Tensor] = None,
-                      dxsum: Optional[Tuple[torch.Tensor, bool]] = None):
+                      dxsum: Optional[Tuple[torch.Tensor, bool]] = None, q8=None):
     """dxsum = (f32 [C], accumulate): also dxsum[c] (+)= sum over samples and pixels of dx -- the bias gradient of the convolution that
     produced x, from the pass that writes dx (theia_layernorm_chw_bwd_colsum)."""
     b, E = x.shape
@@ -625,9 +637,9 @@ def layernorm_chw_bwd(dy, x, gamma, stats, dgamma, dbeta, relu_mask: bool, accum
         ws = torch.empty(need, dtype=torch.float32, device=x.device)
     ds, dC, dacc = (dxsum[0].data_ptr(), dxsum[0].numel(), int(dxsum[1])) if dxsum is not None else (None, 0, 0)
     assert dxsum is None or dxsum[0].dtype == torch.float32
-    N.check(N.lib().theia_layernorm_chw_bwd_colsum(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats.data_ptr(), dx.data_ptr(),
-                                                   dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), b, E, int(relu_mask),
-                                                   int(accumulate), ds, dC, dacc, _dt(x), N.stream_ptr()), "theia_layernorm_chw_bwd")
+    N.check(N.lib().theia_layernorm_chw_bwd_colsum_q8(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats.data_ptr(), dx.data_ptr(),
+                                                      dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), b, E, int(relu_mask),
+                                                      int(accumulate), ds, dC, dacc, _dt(x), _q8(q8), N.stream_ptr()), "theia_layernorm_chw_bwd")
     return dx
 
 
@@ -663,11 +675,11 @@ def distill_loss_fwd(pred: torch.Tensor, target: torch.Tensor, ws: Optional[torc
     return losses, coef
 
 
-def distill_loss_bwd(pred: torch.Tensor, target: torch.Tensor, coef: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+def distill_loss_bwd(pred: torch.Tensor, target: torch.Tensor, coef: torch.Tensor, w: torch.Tensor, q8=None) -> torch.Tensor:
     b, E = pred.shape
     dpred = torch.empty_like(pred)
-    N.check(N.lib().theia_distill_loss_bwd_t(pred.data_ptr(), target.data_ptr(), _dt(target), coef.data_ptr(), w.data_ptr(), dpred.data_ptr(), b,
-                                             E, _dt(pred), N.stream_ptr()), "theia_distill_loss_bwd")
+    N.check(N.lib().theia_distill_loss_bwd_q8(pred.data_ptr(), target.data_ptr(), _dt(target), coef.data_ptr(), w.data_ptr(), dpred.data_ptr(), b,
+                                              E, _dt(pred), _q8(q8), N.stream_ptr()), "theia_distill_loss_bwd")
     return dpred
 
 
