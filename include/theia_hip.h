@@ -147,6 +147,12 @@ typedef struct theia_gemm_args {
      * multiplied by their product before the epilogue.  NULL = 1. */
     const float* a_scale_inv;
     const float* w_scale_inv;
+    /* v11, THEIA_FP8 launches only (else THEIA_ERR_INVALID): `out` ALSO as e4m3, quantised from its bf16-rounded values with *out8_scale
+     * (same pitch / row map as out) -- the next GEMM's operand without a quantisation pass of its own (fc1 -> fc2; fc2's data-gradient
+     * -> fc1's).  NULL = off.  No maximum is recorded (the engine refreshes its delayed scales on the steps that run the separate
+     * passes). */
+    uint8_t* out8;
+    const float* out8_scale;
 } theia_gemm_args_t;
 
 int theia_gemm_nt(const theia_gemm_args_t* args, int dtype, void* stream);

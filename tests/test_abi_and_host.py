@@ -46,7 +46,7 @@ def test_struct_layout_matches_header(tmp_path):
     import subprocess
     from theia_amd import _native as N
     probes = [("theia_rowmap_t", N.RowMap, "in_batch_stride"), ("theia_gemm_args_t", N.GemmArgs, "tile"),
-              ("theia_gemm_args_t", N.GemmArgs, "w_scale_inv"), ("theia_wgrad_args_t", N.WgradArgs, "defer_bias_reduce"),
+              ("theia_gemm_args_t", N.GemmArgs, "w_scale_inv"), ("theia_gemm_args_t", N.GemmArgs, "out8_scale"), ("theia_wgrad_args_t", N.WgradArgs, "defer_bias_reduce"),
               ("theia_cast_job_t", N.CastJob, "first_block")]
     src = "#include <stdio.h>\n#include <stddef.h>\n#include \"theia_hip.h\"\nint main(void){\n"
     for cname, _, field in probes:
@@ -61,7 +61,7 @@ def test_struct_layout_matches_header(tmp_path):
         assert getattr(ct, field).offset == off, f"{cname}.{field}"
     # theia_rowmap_t: 40 int32 then 4 int64; theia_gemm_args_t: 8 pointers, 7 int32 + pad, map, tile + reserved, 3 pointers
     assert C.sizeof(N.RowMap) == 160 + 32
-    assert C.sizeof(N.GemmArgs) == 8 * 8 + 4 * 7 + 4 + C.sizeof(N.RowMap) + 8 + 3 * 8
+    assert C.sizeof(N.GemmArgs) == 8 * 8 + 4 * 7 + 4 + C.sizeof(N.RowMap) + 8 + 5 * 8  # (+ out8, out8_scale: ABI v11)
 
 
 def test_host_side_planning_functions():

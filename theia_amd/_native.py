@@ -50,6 +50,7 @@ class GemmArgs(C.Structure):
         ("tile", C.c_int32), ("reserved", C.c_int32),
         ("ln_sums", C.c_void_p),
         ("a_scale_inv", C.c_void_p), ("w_scale_inv", C.c_void_p),
+        ("out8", C.c_void_p), ("out8_scale", C.c_void_p),
     ]
 
 

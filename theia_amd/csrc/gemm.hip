@@ -368,6 +368,8 @@ extern "C" int theia_gemm_nt(const theia_gemm_args_t* a, int dtype, void* stream
     THEIA_CHECK_ARG((a->act != THEIA_ACT_MUL_DGELU && a->act != THEIA_ACT_MUL_DRELU) || a->aux_in, "theia_gemm_nt: act needs aux_in");
     THEIA_CHECK_ARG(a->rowtab == nullptr || a->rowtab_period > 0, "theia_gemm_nt: rowtab_period");
     THEIA_CHECK_ARG(a->ln_sums == nullptr || a->map.rows_h * a->map.rows_w >= 128, "theia_gemm_nt: ln_sums needs >= 128 rows per image");
+    THEIA_CHECK_ARG(a->out8 == nullptr || (dtype == THEIA_FP8 && a->out8_scale != nullptr && a->ln_sums == nullptr),
+                    "theia_gemm_nt: out8 is an option of THEIA_FP8 launches without ln_sums (with out8_scale)");
     int rc = check_rowmap(a->map, dtype == THEIA_F32 ? 32 : 64, "theia_gemm_nt");
     if (rc) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

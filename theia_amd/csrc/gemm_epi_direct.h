@@ -110,6 +110,8 @@ template <typename T> struct gd_ctx_t {
     bool nok[2];
     float bias8[2][8];
     float alpha;
+    uint8_t* O8;   // fp8 launches: e4m3 copy of the output (theia_gemm_args_t.out8), or NULL
+    float sc8;
     int64_t off_dead;
     int m_split;
     float ls0, lq0, ls1, lq1;
@@ -218,6 +220,12 @@ __device__ __forceinline__ void gd_epilogue_body(gt_f32x4 (&acc)[4][FM], const t
                 if (cx.AUXO != nullptr) store8(live ? cx.AUXO + o : cx.dump, pre);
             }
             store8(live ? cx.O + o : cx.dump, v);
+            if constexpr (SCALE && !SUMS) {  // (fp8 operands only: those launches take this plain loop for every activation)
+                if (cx.O8 != nullptr && live) {
+                    float am_unused = 0.f;
+                    q8_store8(cx.O8, o, v, cx.sc8, am_unused);
+                }
+            }
             if constexpr (SUMS) {
                 float s = 0.f, sq = 0.f;
 #pragma unroll
@@ -264,6 +272,12 @@ __device__ __forceinline__ int gd_epilogue(gt_f32x4 (&acc)[4][FM], const theia_g
         if constexpr (!BIAS_IN_ACC) {
             if (p.bias != nullptr && cx.nok[t]) load8(p.bias + cx.ncol[t], cx.bias8[t]);
         }
+    }
+    cx.O8 = nullptr;
+    cx.sc8 = 0.f;
+    if constexpr (SCALE && !SUMS) {
+        cx.O8 = p.out8;
+        cx.sc8 = p.out8 != nullptr ? *p.out8_scale : 0.f;
     }
     cx.alpha = 1.0f;
     if constexpr (SCALE) cx.alpha = (p.a_scale_inv != nullptr ? *p.a_scale_inv : 1.0f) * (p.w_scale_inv != nullptr ? *p.w_scale_inv : 1.0f);

@@ -130,7 +130,7 @@ class Fp8Scales:
         self.index: Dict[str, int] = {}
         self.calibrated: set = set()
         self.steps = 0                                                          # update() calls so far
-        self.refresh = max(1, int(os.environ.get("THEIA_FP8_AMAX_EVERY", "16")))  # every refresh-th step records maxima (see fused())
+        self.refresh = max(1, int(os.environ.get("THEIA_FP8_AMAX_EVERY", "32")))  # every refresh-th step records maxima (see fused())
 
     def slot(self, site: str) -> int:
         i = self.index.get(site)
@@ -152,7 +152,7 @@ class Fp8Scales:
         # (between refresh steps the pass does not record the maximum either: its one atomic per block is ~10 us of a 12-50 us pass)
         return ops.quantize_fp8(x2d, sc, am if self.steps % self.refresh == 0 else None), inv
 
-    def fused(self, site: str, like: torch.Tensor):
+    def fused(self, site: str, like, records_max: bool = True):
         """(e4m3 buffer shaped like `like`, scale, amax, inv_scale) for a producer that writes its output's e4m3 copy itself (the *_q8
         passes: ops.layernorm_fwd(..., q8=) ...), or None while the site has not calibrated itself through quantize() yet (its first
         step) -- round 6: the separate 3-byte-per-element pass becomes one more byte written by the pass that produces the tensor"""
@@ -160,11 +160,16 @@ class Fp8Scales:
         # and serialised per address (the effect that made the stand-alone pass take 90-105 us, above) -- with them the fused LayerNorm passes
         # were 0.4 ms per step SLOWER than the separate quantise passes.  Instead every `refresh`-th step runs the separate passes (which
         # record the maxima and so refresh the scales); in between the scales stay as they are -- delayed scaling with an update interval,
-        # e4m3 saturation (+-448) under it as always.  THEIA_FP8_AMAX_EVERY (default 16).
-        if site not in self.calibrated or self.steps % self.refresh == 0:
+        # e4m3 saturation (+-448) under it as always.  THEIA_FP8_AMAX_EVERY (default 32).
+        # On the refresh steps the producers that CAN record the maximum (the *_q8 passes) do, atomics and all -- a slower pass once in
+        # `refresh` steps; the GEMM epilogues cannot (records_max=False): their consumers run the separate pass on those steps.
+        refresh_step = self.steps % self.refresh == 0
+        if site not in self.calibrated or (refresh_step and not records_max):
             return None
         i = self.slot(site)
-        return (torch.empty(like.shape, dtype=torch.float8_e4m3fn, device=like.device), self.scale[i:i + 1], None, self.inv[i:i + 1])
+        shape, dev = (like.shape, like.device) if isinstance(like, torch.Tensor) else like
+        return [torch.empty(shape, dtype=torch.float8_e4m3fn, device=dev), self.scale[i:i + 1], self.amax[i:i + 1] if refresh_step else None,
+                self.inv[i:i + 1]]
 
     def update(self, activations_only: bool = False) -> None:
         """amax -> next scale / inverse scale.  activations_only: leave the weight ("w:") slots alone -- their e4m3 copies in the
@@ -515,26 +520,35 @@ class StudentEngine:
             return None
         return self._q8_for(wkey, like)
 
-    def _q8_for(self, key: str, like: torch.Tensor):
+    def _q8_for(self, key: str, like, records_max: bool = True):
         """the e4m3 side output a producer should write for the GEMM input of operand `key` (fp8 mode, site calibrated), else None"""
-        if self.fp8 is None or key + ".f8" not in self._opcache or like.dtype != torch.bfloat16 or not like.is_contiguous():
+        if self.fp8 is None or key + ".f8" not in self._opcache:
+            return None
+        if isinstance(like, torch.Tensor) and (like.dtype != torch.bfloat16 or not like.is_contiguous()):
             return None
         if os.environ.get("THEIA_FP8_FUSED_QUANT", "1") == "0":  # A/B switch: every GEMM input through its own quantise pass
             return None
-        return self.fp8.fused("x:" + key, like)
+        return self.fp8.fused("x:" + key, like, records_max)
 
     def _mm(self, x: torch.Tensor, key: str, bias: Optional[torch.Tensor] = None, x8=None, **epi) -> torch.Tensor:
         """x [M, K] @ operand `key`^T with the epilogue `epi`: fp8 operands when the engine runs in fp8 mode and the operand has an
         e4m3 copy (K a multiple of 64, N >= 64), bf16 / f32 otherwise.  x8: what _q8_for(key, x) returned when x's producer already
         wrote the e4m3 copy."""
         oc = self._opcache
+        use_fp8 = epi.pop("fp8", True)  # False: this launch keeps its bf16 operands in fp8 mode too (see the attention call sites)
+        out8 = epi.pop("out8", None)  # _q8_for(<the consumer's key>, ((M, N), device)): this launch's output also as e4m3 -- fp8 launches only
+        o8 = (out8[0], out8[1]) if out8 is not None else None
+        if x8 is not None and x8[0] is None:
+            x8 = None  # (its producer ran on bf16 operands and could not write it)
         if x8 is not None and "out" not in epi:
-            return ops.linear(x8[0].view(x.shape), oc[key + ".f8"], bias, scale_inv=(x8[3], oc[key + ".inv"]), **epi)
+            return ops.linear(x8[0].view(x.shape), oc[key + ".f8"], bias, scale_inv=(x8[3], oc[key + ".inv"]), out8=o8, **epi)
         # (the fp8 operands exist for the persistent kernel only, which addresses M < 2^24 rows: beyond that -- a head's 64x64 maps at
         # b >= 4096 per GPU -- the launch keeps its bf16 operands instead of failing in the middle of a step)
-        if self.fp8 is not None and key + ".f8" in oc and "out" not in epi and x.shape[0] < (1 << 24):
+        if use_fp8 and self.fp8 is not None and key + ".f8" in oc and "out" not in epi and x.shape[0] < (1 << 24):
             x8, inv = self.fp8.quantize(x, "x:" + key)
-            return ops.linear(x8, oc[key + ".f8"], bias, scale_inv=(inv, oc[key + ".inv"]), **epi)
+            return ops.linear(x8, oc[key + ".f8"], bias, scale_inv=(inv, oc[key + ".inv"]), out8=o8, **epi)
+        if out8 is not None:
+            out8[0] = None  # a bf16 launch: the consumer quantises its input itself
         return ops.linear(x, oc[key], bias, **epi)
 
     def _build_operand_table(self, device):
@@ -679,12 +693,15 @@ class StudentEngine:
             a, mean1, rstd1 = ops.layernorm_fwd(h, L.layernorm_before.weight, L.layernorm_before.bias, LN_EPS_VIT, q8=q8a[:3] if q8a is not None else None)
             qkv = self._mm(a, f"l{i}.wqkv", oc[f"l{i}.bqkv"], x8=q8a)
             o, lse = ops.attention_fwd(qkv, b, NTOK, nh)
-            h1 = self._mm(o, f"l{i}.wo", L.attention.o_proj.bias, resid=h)
+            # (fp8 mode: the attention kernels write bf16 only, and a quantisation pass over o -- or over dQKV in backward -- costs more than
+            # e4m3 operands save on these K = D / 3D launches: they keep their bf16 operands)
+            h1 = self._mm(o, f"l{i}.wo", L.attention.o_proj.bias, resid=h, fp8=False)
             q8m = self._q8_for(f"l{i}.w1", h1)
             m, mean2, rstd2 = ops.layernorm_fwd(h1, L.layernorm_after.weight, L.layernorm_after.bias, LN_EPS_VIT, q8=q8m[:3] if q8m is not None else None)
             pre = torch.empty(M, F, dtype=T, device=dev) if save else None
-            act = self._mm(m, f"l{i}.w1", L.mlp.fc1.bias, x8=q8m, act=N.ACT_GELU, aux_out=pre)
-            h2 = self._mm(act, f"l{i}.w2", L.mlp.fc2.bias, resid=h1)
+            q8act = self._q8_for(f"l{i}.w2", ((M, F), dev), records_max=False)  # (fp8 mode: fc1's epilogue also writes the e4m3 operand of fc2)
+            act = self._mm(m, f"l{i}.w1", L.mlp.fc1.bias, x8=q8m, act=N.ACT_GELU, aux_out=pre, out8=q8act)
+            h2 = self._mm(act, f"l{i}.w2", L.mlp.fc2.bias, x8=q8act, resid=h1)
             if save:
                 saved["layers"].append((h, mean1, rstd1, a, qkv, o, lse, h1, mean2, rstd2, m, pre, act))
             h = h2
@@ -750,10 +767,11 @@ class StudentEngine:
             saved["layers"][i] = None
             # h2 = h1 + fc2(act)
             wgrad_later(dh, act, L.mlp.fc2)
-            dpre = self._mm(dh, f"l{i}.w2T", None, x8=q8dh, act=N.ACT_MUL_DGELU, aux_in=pre)
+            q8dpre = self._q8_for(f"l{i}.w1T", ((M, F), dev), records_max=False)
+            dpre = self._mm(dh, f"l{i}.w2T", None, x8=q8dh, act=N.ACT_MUL_DGELU, aux_in=pre, out8=q8dpre)
             del act, pre
             wgrad_later(dpre, m, L.mlp.fc1)
-            dm = self._mm(dpre, f"l{i}.w1T")
+            dm = self._mm(dpre, f"l{i}.w1T", x8=q8dpre)
             del dpre
             q8dh1 = self._q8_for(f"l{i}.woT", dm)
             dh1 = self._ln_bwd(dm, h1, L.layernorm_after, mean2, rstd2, dh, ws, q8=q8dh1)
@@ -772,7 +790,7 @@ class StudentEngine:
                 for j, prj in enumerate(qkv_mods):
                     sl = dqkv[:, j * D:(j + 1) * D]
                     wgrad(sl, a, prj.weight, prj.bias)
-            da = self._mm(dqkv, f"l{i}.wqkvT")
+            da = self._mm(dqkv, f"l{i}.wqkvT", fp8=False)
             del dqkv
             q8dh = self._q8_for(f"l{i - 1}.w2T", da) if i > 0 else None
             dh = self._ln_bwd(da, h, L.layernorm_before, mean1, rstd1, dh1, ws, q8=q8dh)

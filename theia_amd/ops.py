@@ -149,8 +149,9 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int
             bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, act: int = N.ACT_NONE,
             aux_in: Optional[torch.Tensor] = None, aux_out: Optional[torch.Tensor] = None,
             rowtab: Optional[torch.Tensor] = None, rowtab_period: int = 0, tile: int = 0, plan_only: bool = False,
-            ln_sums: Optional[torch.Tensor] = None, scale_inv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
-    """tile: kernel request (0 = the library's choice; see theia_gemm_args_t.tile).  plan_only: launch nothing, return the code
+            ln_sums: Optional[torch.Tensor] = None, scale_inv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, out8=None):
+    """out8 = (e4m3 tensor like out, scale [1]): fp8 launches also write their output as e4m3 (theia_gemm_args_t.out8).
+    tile: kernel request (0 = the library's choice; see theia_gemm_args_t.tile).  plan_only: launch nothing, return the code
     of the kernel the library would run (theia_gemm_nt_plan)."""
     g = GemmArgs()
     g.a, g.w, g.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
@@ -164,6 +165,9 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int
         assert w.dtype == torch.float8_e4m3fn and out.dtype == torch.bfloat16
         if scale_inv is not None:
             g.a_scale_inv, g.w_scale_inv = scale_inv[0].data_ptr(), scale_inv[1].data_ptr()
+        if out8 is not None:
+            assert out8[0].dtype == torch.float8_e4m3fn and out8[0].numel() == out.numel()
+            g.out8, g.out8_scale = out8[0].data_ptr(), out8[1].data_ptr()
         tile = 0 if tile in (0, 256256) else tile
     if tile == 0 and GEMM_TILE_HINT != 0 and a.dtype != torch.float8_e4m3fn:
         if GEMM_TILE_HINT == 128128:
@@ -193,14 +197,15 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
            act: int = N.ACT_NONE, aux_in: Optional[torch.Tensor] = None, aux_out: Optional[torch.Tensor] = None,
-           out: Optional[torch.Tensor] = None, tile: int = 0, scale_inv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, tile: int = 0, scale_inv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+           out8=None) -> torch.Tensor:
     """out = act(x @ w.T + bias) + resid ; x [M,K], w [N,K] contiguous.  fp8 operands (float8_e4m3fn, with scale_inv) -> bf16 out."""
     M, K = x.shape
     Nn = w.shape[0]
     if out is None:
         out = torch.empty(M, Nn, dtype=torch.bfloat16 if x.dtype == torch.float8_e4m3fn else x.dtype, device=x.device)
     return gemm_nt(x, w, out, M, Nn, K, rm_plain(K, x.stride(0), out.stride(0)), w.stride(0), out.stride(0), bias, resid, act,
-                   aux_in, aux_out, tile=tile, scale_inv=scale_inv)
+                   aux_in, aux_out, tile=tile, scale_inv=scale_inv, out8=out8)
 
 
 def quantize_fp8(x: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
