@@ -532,9 +532,9 @@ def test_fp8_mode_tracks_the_oracle(bb):
         assert rel(float(losses[k]), float(ref_losses[k])) < 5e-2, (k, float(losses[k]), float(ref_losses[k]))
     cos, nr, who = _grad_agreement(model, grads)
     print(f"[fp8 {bb}] worst gradient cosine {cos:.4f} ({who}), worst norm-ratio error {nr:.3f}")
-    # (DeiT-tiny: 0.898-0.91 on the value projections of the upper layers depending on the rounding realisation -- round 3's
-    # accumulation-order change moved it from just above to just below 0.9; DeiT-small / base sit at 0.93+)
-    assert cos > 0.88 and nr < 0.15, (cos, nr, who)
+    # (round 6: DeiT-tiny 0.918 -- the 3x3 convolutions and the attention-adjacent projections keep bf16 operands now; rounds 3-5: 0.898-0.91 with
+    # a gate of 0.88; DeiT-small / base sit at 0.93+)
+    assert cos > 0.9 and nr < 0.15, (cos, nr, who)
 
 
 @pytest.mark.parametrize("key", ["g1", "g2"])
@@ -733,3 +733,59 @@ def test_headline_model_training_tracks_the_oracle_over_three_steps():
     assert all(b < a for a, b in zip(ref, ref[1:])) and all(b < a for a, b in zip(curves["bf16"], curves["bf16"][1:]))
     assert d32[0] < 1e-4 and max(d32) < 2e-3, (curves["fp32"], ref)
     assert d16[0] < 2e-3 and max(d16) < 1e-2, (curves["bf16"], ref)
+
+
+def test_fp8_training_tracks_the_fp32_oracle_trajectory_on_deit_small():
+    """BASELINE configs[3]'s student against the ORACLE over optimizer steps (round-5 review item 4): DeiT-small + cdiv, B = 4, 20 AdamW steps
+    at lr 2e-4 on one fixed batch -- the CPU oracle in fp32 with the written-out AdamW of the trajectory tests above, the engine in fp8
+    mode (e4m3 operands with delayed per-tensor scales refreshed every 32nd step, quantisation fused into the producers, bf16
+    weight-gradient / attention-adjacent / 3x3-kernel launches) and, for scale, in bf16.  Gates: fp8 within 2e-2 of the oracle's loss at
+    every step and 5e-3 at the first, the same total decrease within 10 %; bf16 under the same 2e-2 (it measures 1.2e-2 here: on this
+    over-fitting run of 4 images the loss curve has a kink at step 6 where any rounding realisation lands slightly differently)."""
+    from theia_amd.optimizers import FusedAdamW
+    from theia_amd.optimizers.utils import is_no_decay
+    bb, teachers, B, steps = "facebook/deit-small-patch16-224", O.TEACHER_SETS["cdiv"], 4, 20
+    lr, b1, b2, eps, wd = 2e-4, 0.9, 0.999, 1e-8, 0.01
+    images = O.synth_images(B, 0)
+    tcpu = O.synth_targets(B, teachers, 1)
+    targets = {t: v.to("cuda:0") for t, v in tcpu.items()}
+    curves = {}
+    for prec in ("bf16", "fp8"):
+        model, params = build(bb, teachers, prec)
+        opt = FusedAdamW(model, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
+        got = []
+        for _ in range(steps):
+            opt.zero_grad()
+            losses = model.get_loss(model(images), targets, as_float=False)
+            main = 0.9 * losses["cos_loss"] + 0.1 * losses["l1_loss"]
+            main.backward()
+            opt.step()
+            got.append(float(main))
+        curves[prec] = got
+        del model, opt
+        torch.cuda.empty_cache()
+    ref = []
+    P = {k: v.clone() for k, v in params.items()}
+    M = {k: torch.zeros_like(v) for k, v in P.items()}
+    V = {k: torch.zeros_like(v) for k, v in P.items()}
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    for t in range(1, steps + 1):
+        _l, main, grads, _p = O.train_step_grads(P, images, tcpu, bb, teachers, "cos_l1")
+        ref.append(float(main))
+        for k in P:
+            gk = grads[k]
+            decay = 0.0 if is_no_decay(k, P[k]) else wd
+            P[k].mul_(1.0 - lr * decay)
+            M[k].mul_(b1).add_(gk, alpha=1.0 - b1)
+            V[k].mul_(b2).addcmul_(gk, gk, value=1.0 - b2)
+            denom = (V[k] / (1.0 - b2 ** t)).sqrt_().add_(eps)
+            P[k].addcdiv_(M[k] / (1.0 - b1 ** t), denom, value=-lr)
+    d8 = [abs(a - b) / abs(b) for a, b in zip(curves["fp8"], ref)]
+    d16 = [abs(a - b) / abs(b) for a, b in zip(curves["bf16"], ref)]
+    print(f"[fp8 trajectory, DeiT-small] oracle {ref[0]:.5f} -> {ref[-1]:.5f}; fp8 {curves['fp8'][0]:.5f} -> {curves['fp8'][-1]:.5f}, worst step "
+          f"deviation {max(d8):.2e} (first {d8[0]:.2e}); bf16 worst {max(d16):.2e}")
+    drop = ref[0] - ref[-1]
+    assert drop > 0.01 and ref[-1] < ref[0]
+    assert d8[0] < 5e-3 and max(d8) < 2e-2, (curves["fp8"], ref)
+    assert max(d16) < 2e-2, (curves["bf16"], ref)
+    assert abs((curves["fp8"][0] - curves["fp8"][-1]) - drop) < 0.10 * drop
