@@ -705,7 +705,8 @@ def _main(argv=None):
             "metric": METRIC,
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "fp8": "fp8 e4m3 operands (fwd + dgrad GEMMs), f32 accumulate, bf16 out; bf16 wgrad"}.get(args.precision, "f32"),
+            "dtype": {"bf16": "bf16", "fp8": "fp8 e4m3 operands (forward + data-gradient GEMMs of the linears and transposed convolutions; the one-image-per-tile 3x3 "
+                             "convolutions, the attention-adjacent projections and every weight gradient keep bf16 operands), f32 accumulate, bf16 out"}.get(args.precision, "f32"),
             "data": "synthetic",
             "config": {"workload": f"{args.backbone.split('/')[-1]} student + {len(TEACHERS)} teacher{'s' if len(TEACHERS) > 1 else ''} ({args.teachers}), per-GPU batch {b}, "
                                    f"teacher features resident as {'bf16' if teacher_dtype == torch.bfloat16 else 'fp32'}, "

@@ -21,10 +21,9 @@ python bench.py --mode forward_feature > $O/forward_feature_b4096.json 2> /dev/n
 python bench.py --backbone facebook/deit-small-patch16-224 --teachers cdiv --batch 16 --steps 50 --warmup 5 --no-cpu-baseline > $O/small_cdiv_b16_eager.json 2> /dev/null
 python bench.py --backbone facebook/deit-small-patch16-224 --teachers cdiv --batch 16 --steps 50 --warmup 5 --no-cpu-baseline --graph > $O/small_cdiv_b16_graph.json 2> /dev/null
 python bench.py --backbone facebook/deit-tiny-patch16-224 --teachers cdiv --batch 256 --steps 30 --warmup 5 --no-cpu-baseline --graph > $O/tiny_cdiv_b256_graph.json 2> /dev/null
-python bench.py --backbone facebook/deit-small-patch16-224 --batch 256 --steps 20 --warmup 5 --no-cpu-baseline --precision fp8 > $O/small_5t_b256_fp8.json 2> $O/small_fp8.err
 # the other workloads: serial kernel traces, PMC traffic (into profiles/ first), then their self-checked lines
 cd /tmp
-for cfg in "tiny_cdiv_b256:--backbone facebook/deit-tiny-patch16-224 --teachers cdiv --batch 256" "small_5t_b256:--backbone facebook/deit-small-patch16-224 --batch 256"; do n=${cfg%%:*}; a=${cfg#*:}
+for cfg in "tiny_cdiv_b256:--backbone facebook/deit-tiny-patch16-224 --teachers cdiv --batch 256" "small_5t_b256:--backbone facebook/deit-small-patch16-224 --batch 256" "small_5t_b256_fp8:--backbone facebook/deit-small-patch16-224 --batch 256 --precision fp8"; do n=${cfg%%:*}; a=${cfg#*:}
   THEIA_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$n -o bench -- python $R/bench.py $a --steps 8 --warmup 2 --no-roofline --no-cpu-baseline --no-selfcheck > $O/prof_$n.log 2>&1
   python $R/tools/rocpd_stats.py $(ls $O/prof_$n/*.db | head -1) --csv $O/kernel_stats_serial_$n.csv --top 45 > $O/kernel_stats_serial_$n.txt; rm -rf $O/prof_$n
   PMC_BENCH_ARGS="$a" bash $R/tools/pmc_bench_traffic.sh $O/pmc_$n > $O/pmc_$n.log 2>&1
@@ -35,6 +34,19 @@ done
 cd $R
 python bench.py --backbone facebook/deit-tiny-patch16-224 --teachers cdiv --batch 256 --steps 30 --warmup 5 --no-cpu-baseline > $O/tiny_cdiv_b256.json 2> $O/tiny.err
 python bench.py --backbone facebook/deit-small-patch16-224 --batch 256 --steps 20 --warmup 5 --no-cpu-baseline > $O/small_5t_b256_bf16.json 2> $O/small.err
+# BASELINE configs[3]: fp8 against bf16, arms alternating (64 steps: two scale-refresh steps inside the timed region)
+for r in 1 2 3; do
+  python bench.py --backbone facebook/deit-small-patch16-224 --batch 256 --steps 64 --warmup 5 --no-cpu-baseline --precision fp8 > $O/small_5t_b256_fp8_$r.json 2> $O/small_fp8.err
+  python bench.py --backbone facebook/deit-small-patch16-224 --batch 256 --steps 64 --warmup 5 --no-cpu-baseline > $O/small_5t_b256_bf16_$r.json 2> /dev/null
+done
+cp $O/small_5t_b256_fp8_3.json $O/small_5t_b256_fp8.json
+python bench.py --precision fp8 --steps 64 --warmup 5 --no-cpu-baseline > $O/base_5t_b128_fp8.json 2> /dev/null
+python bench.py --steps 64 --warmup 5 --no-cpu-baseline > $O/base_5t_b128_bf16_64steps.json 2> /dev/null
+python -c "
+import json
+for f in ['small_5t_b256_fp8_%d' % r for r in (1, 2, 3)] + ['small_5t_b256_bf16_%d' % r for r in (1, 2, 3)] + ['base_5t_b128_fp8', 'base_5t_b128_bf16_64steps']:
+    d=json.load(open('$O/'+f+'.json')); print(f, d['value'], d['ms_per_step'], (d.get('roofline') or {}).get('traffic'))
+"
 python -c "
 import json
 for f in ('tiny_cdiv_b256','small_5t_b256_bf16'):
