@@ -275,8 +275,13 @@ def selfcheck_dispatch(fwd_bwd, engine):
     rel = abs(la - lb) / abs(lb)
     # a single wrong tensor inside a large bucket cannot hide behind the bucket cosine: every tensor of >= 4096 elements > 0.98 (the gate
     # of the model-level tests at their small batches; 0.9938 measured at the benched batch), the failing tensor is named
-    return {"ok": bool(rel < 2e-3 and worst > 0.99 and worst_t > 0.98), "loss_rel_diff": float(f"{rel:.3e}"), "worst_bucket_cosine": round(worst, 6),
-            "worst_tensor_cosine": round(worst_t, 6), "worst_tensor": worst_name, "tensor_gate": 0.98}
+    # fp8 mode: the launches that keep bf16 operands (3x3 kernel, attention-adjacent projections, weight gradients) move to the 2-stage
+    # kernels under the hint, and a one-ulp bf16 difference upstream flips e4m3 roundings (3 mantissa bits) downstream: the two executions
+    # decorrelate to the e4m3 noise floor instead of the bf16 one (0.969-0.976 measured; the mode's own gate against the oracle is 0.9)
+    fp8 = getattr(engine, "precision", "") == "fp8"
+    gate_b, gate_t = (0.95, 0.93) if fp8 else (0.99, 0.98)
+    return {"ok": bool(rel < 2e-3 and worst > gate_b and worst_t > gate_t), "loss_rel_diff": float(f"{rel:.3e}"), "worst_bucket_cosine": round(worst, 6),
+            "worst_tensor_cosine": round(worst_t, 6), "worst_tensor": worst_name, "bucket_gate": gate_b, "tensor_gate": gate_t}
 
 
 def selfcheck_gemm_ulp(batch, dev):

@@ -912,19 +912,20 @@ extern "C" int theia_distill_loss_fwd(const void* pred, const float* target, flo
     return theia_distill_loss_fwd_t(pred, target, THEIA_F32, losses, coef, workspace, b, E, dtype, stream);
 }
 
-template <typename T, typename TQ = float>
+// Q8: also the e4m3 copy of dpred (theia_distill_loss_bwd_q8) -- a separate instantiation whose blocks stride over a sample's elements (at
+// most 32 blocks per sample: that form ends with one reduction of the maxima per wave, see q8_flush_wave); the plain instantiation is the
+// round-5 kernel (one 8-element vector per thread), so the f32 parity mode's gradients are what they were.
+template <typename T, typename TQ = float, bool Q8 = false>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pred, const TQ* __restrict__ target,
                                                        const float* __restrict__ coef, const float* __restrict__ w,
                                                        T* __restrict__ dpred, int b, int64_t E, const theia_q8_out_t q8) {
-    // blockIdx.y = sample; the blocks of a sample stride over its E elements (at most 32 blocks per sample: the e4m3 path ends with one
-    // conditional atomic per wave, see q8_flush_wave)
     const int sample = blockIdx.y;
-    const float inv_n = 1.0f / ((float)b * (float)E);
-    const float wm = w[0] * 2.0f * inv_n, wc = w[1], wl = w[2] * inv_n;
-    const float alpha = wc * coef[2 * sample], beta = wc * coef[2 * sample + 1];
-    const float qsc = q8.out != nullptr ? *q8.scale : 0.f;
-    float qam = 0.f;
-    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; e < E; e += (int64_t)gridDim.x * 256 * 8) {
+    if constexpr (!Q8) {
+        const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+        if (e >= E) return;
+        const float inv_n = 1.0f / ((float)b * (float)E);
+        const float wm = w[0] * 2.0f * inv_n, wc = w[1], wl = w[2] * inv_n;
+        const float alpha = wc * coef[2 * sample], beta = wc * coef[2 * sample + 1];
         float p[8], q[8], o[8];
         load8(pred + (int64_t)sample * E + e, p);
         load8(target + (int64_t)sample * E + e, q);
@@ -934,9 +935,26 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pre
             o[j] = wm * d + wl * fminf(fmaxf(d, -1.0f), 1.0f) + beta * p[j] - alpha * q[j];
         }
         store8(dpred + (int64_t)sample * E + e, o);
-        if (q8.out != nullptr) q8_store8(q8.out, (int64_t)sample * E + e, o, qsc, qam);
+    } else {
+        const float inv_n = 1.0f / ((float)b * (float)E);
+        const float wm = w[0] * 2.0f * inv_n, wc = w[1], wl = w[2] * inv_n;
+        const float alpha = wc * coef[2 * sample], beta = wc * coef[2 * sample + 1];
+        const float qsc = *q8.scale;
+        float qam = 0.f;
+        for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; e < E; e += (int64_t)gridDim.x * 256 * 8) {
+            float p[8], q[8], o[8];
+            load8(pred + (int64_t)sample * E + e, p);
+            load8(target + (int64_t)sample * E + e, q);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = p[j] - q[j];
+                o[j] = wm * d + wl * fminf(fmaxf(d, -1.0f), 1.0f) + beta * p[j] - alpha * q[j];
+            }
+            store8(dpred + (int64_t)sample * E + e, o);
+            q8_store8(q8.out, (int64_t)sample * E + e, o, qsc, qam);
+        }
+        q8_flush_wave(q8.amax, qam);
     }
-    if (q8.out != nullptr) q8_flush_wave(q8.amax, qam);
 }
 extern "C" int theia_distill_loss_bwd_t(const void* pred, const void* target, int target_dtype, const float* coef, const float* w, void* dpred,
                                         int b, int64_t E, int dtype, void* stream) {
@@ -946,8 +964,12 @@ extern "C" int theia_distill_loss_bwd_t(const void* pred, const void* target, in
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const theia_q8_out_t q8 = q8_take();
     const int64_t bx = (E / 8 + 255) / 256;
-    const dim3 grid((unsigned)(bx < 32 ? bx : 32), b);
-    if (target_dtype == THEIA_BF16) {
+    const dim3 grid((unsigned)bx, b), grid8((unsigned)(bx < 32 ? bx : 32), b);
+    if (q8.out != nullptr && target_dtype == THEIA_BF16) {
+        hipLaunchKernelGGL((loss_bwd_kernel<bf16_t, bf16_t, true>), grid8, dim3(256), 0, s, (const bf16_t*)pred, (const bf16_t*)target, coef, w, (bf16_t*)dpred, b, E, q8);
+    } else if (q8.out != nullptr) {
+        hipLaunchKernelGGL((loss_bwd_kernel<bf16_t, float, true>), grid8, dim3(256), 0, s, (const bf16_t*)pred, (const float*)target, coef, w, (bf16_t*)dpred, b, E, q8);
+    } else if (target_dtype == THEIA_BF16) {
         hipLaunchKernelGGL((loss_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)pred, (const bf16_t*)target, coef, w, (bf16_t*)dpred, b, E, q8);
     } else {
         DISPATCH_T(dtype, hipLaunchKernelGGL((loss_bwd_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const bf16_t*)pred, (const float*)target, coef, w, (bf16_t*)dpred, b, E, q8),

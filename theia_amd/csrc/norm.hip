@@ -12,14 +12,18 @@ constexpr int LN_MAXV = 4;  // 8-element vectors per lane
 
 // NV = 8-element vectors per lane: 2 for D <= 1024 (the ViT widths), else NV -- the row and, in backward, the per-lane
 // dgamma/dbeta accumulators live in registers, so NV sets the register count (backward: 226 VGPRs at NV = 4).
-template <typename T, int NV>
+// Q8: also the e4m3 copy of y (theia_layernorm_fwd_q8).  A separate instantiation: with the side output as a run-time branch of the one kernel
+// the compiler contracted the affine expression differently and the f32 parity mode's outputs moved by an ulp (3.5e-6 on the predictions --
+// enough to push a sampled gradient of the G5 golden test from 2.9e-3 to 5.8e-3 of its tensor's RMS): the plain instantiation is the
+// round-5 kernel, instruction for instruction.
+template <typename T, int NV, bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_row_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ y,
                                                          float* __restrict__ mean, float* __restrict__ rstd, int64_t M,
                                                          int D, float eps, const theia_q8_out_t q8) {
     const int lane = threadIdx.x & 63;
-    const float qsc = q8.out != nullptr ? *q8.scale : 0.f;
-    float qam = 0.f;
+    float qsc = 0.f, qam = 0.f;
+    if constexpr (Q8) qsc = *q8.scale;
     const int nv = D >> 3;
     const float invD = 1.0f / (float)D;
     // Every load is unconditional, from a vector index clamped into the row (lanes past the row mask their contribution with a select),
@@ -72,14 +76,16 @@ __global__ __launch_bounds__(256) void ln_row_fwd_kernel(const T* __restrict__ x
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * g8[i][j] + b8[i][j];  // (outside the mask: a use under it would pull the loads in)
             if (ok[i]) store8(y + row * D + vc[i] * 8, o);
-            if (q8.out != nullptr && ok[i]) q8_store8(q8.out, row * D + vc[i] * 8, o, qsc, qam);
+            if constexpr (Q8) {
+                if (ok[i]) q8_store8(q8.out, row * D + vc[i] * 8, o, qsc, qam);
+            }
         }
         if (lane == 0) {
             mean[row] = mu;
             rstd[row] = rs;
         }
     }
-    if (q8.out != nullptr) q8_flush_wave(q8.amax, qam);
+    if constexpr (Q8) q8_flush_wave(q8.amax, qam);
 }
 
 extern "C" int theia_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
@@ -93,12 +99,14 @@ extern "C" int theia_layernorm_fwd(const void* x, const float* gamma, const floa
     // 8-element vectors per lane: 1 for D <= 512 (DeiT-small / -tiny: a second, fully masked vector would still be loaded -- the loads are
     // unconditional), 2 for D <= 1024, else LN_MAXV
     const int nvl = D <= 512 ? 1 : D <= 1024 ? 2 : LN_MAXV;
-#define LN_FWD_LAUNCH(TT, NVV)                                                                                                            \
-    hipLaunchKernelGGL((ln_row_fwd_kernel<TT, NVV>), dim3(blocks), dim3(256), 0, s, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, M, D, eps, q8)
-    if (dtype == THEIA_BF16) {
-        if (nvl == 1) LN_FWD_LAUNCH(bf16_t, 1); else if (nvl == 2) LN_FWD_LAUNCH(bf16_t, 2); else LN_FWD_LAUNCH(bf16_t, LN_MAXV);
+#define LN_FWD_LAUNCH(TT, NVV, QQ)                                                                                                            \
+    hipLaunchKernelGGL((ln_row_fwd_kernel<TT, NVV, QQ>), dim3(blocks), dim3(256), 0, s, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, M, D, eps, q8)
+    if (dtype == THEIA_BF16 && q8.out != nullptr) {
+        if (nvl == 1) LN_FWD_LAUNCH(bf16_t, 1, true); else if (nvl == 2) LN_FWD_LAUNCH(bf16_t, 2, true); else LN_FWD_LAUNCH(bf16_t, LN_MAXV, true);
+    } else if (dtype == THEIA_BF16) {
+        if (nvl == 1) LN_FWD_LAUNCH(bf16_t, 1, false); else if (nvl == 2) LN_FWD_LAUNCH(bf16_t, 2, false); else LN_FWD_LAUNCH(bf16_t, LN_MAXV, false);
     } else if (dtype == THEIA_F32) {
-        if (nvl == 1) LN_FWD_LAUNCH(float, 1); else if (nvl == 2) LN_FWD_LAUNCH(float, 2); else LN_FWD_LAUNCH(float, LN_MAXV);
+        if (nvl == 1) LN_FWD_LAUNCH(float, 1, false); else if (nvl == 2) LN_FWD_LAUNCH(float, 2, false); else LN_FWD_LAUNCH(float, LN_MAXV, false);
     } else
         THEIA_CHECK_ARG(false, "theia_layernorm_fwd: bad dtype %d", dtype);
 #undef LN_FWD_LAUNCH
@@ -113,15 +121,15 @@ extern "C" int theia_layernorm_fwd_q8(const void* x, const float* gamma, const f
 
 // backward: dx per row (wave); dgamma/dbeta accumulated per lane over the rows this wave visits, then
 // block-reduced through LDS and written as one partial row per block; a second kernel sums the partials.
-template <typename T, int NV, bool HAS_RES>
+template <typename T, int NV, bool HAS_RES, bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_row_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const T* __restrict__ dres,
                                                          T* __restrict__ dx, float* __restrict__ part, int64_t M, int D,
                                                          const theia_q8_out_t q8) {
     extern __shared__ float red[];  // [4][2*D]
-    const float qsc = q8.out != nullptr ? *q8.scale : 0.f;
-    float qam = 0.f;
+    float qsc = 0.f, qam = 0.f;
+    if constexpr (Q8) qsc = *q8.scale;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 3;
     const float invD = 1.0f / (float)D;
@@ -177,10 +185,12 @@ __global__ __launch_bounds__(256) void ln_row_bwd_kernel(const T* __restrict__ d
                 for (int j = 0; j < 8; ++j) o[j] += rr[i][j];
             }
             if (ok[i]) store8(dx + row * D + vc[i] * 8, o);
-            if (q8.out != nullptr && ok[i]) q8_store8(q8.out, row * D + vc[i] * 8, o, qsc, qam);
+            if constexpr (Q8) {
+                if (ok[i]) q8_store8(q8.out, row * D + vc[i] * 8, o, qsc, qam);
+            }
         }
     }
-    if (q8.out != nullptr) q8_flush_wave(q8.amax, qam);
+    if constexpr (Q8) q8_flush_wave(q8.amax, qam);
     float* mine = red + wave * 2 * D;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -258,7 +268,11 @@ extern "C" int theia_layernorm_bwd(const void* dy, const void* x, const float* g
     const theia_q8_out_t q8 = q8_take();
     const int nvl = D <= 512 ? 1 : D <= 1024 ? 2 : LN_MAXV;  // (see theia_layernorm_fwd)
 #define LN_BWD_LAUNCH(TT, NVV, RR)                                                                                                      \
-    hipLaunchKernelGGL((ln_row_bwd_kernel<TT, NVV, RR>), dim3(blocks), dim3(256), lds, s, (const TT*)dy, (const TT*)x, gamma, mean, rstd, \
+    if (q8.out != nullptr && sizeof(TT) == 2)                                                                                          \
+        hipLaunchKernelGGL((ln_row_bwd_kernel<bf16_t, NVV, RR, true>), dim3(blocks), dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, \
+                           (const bf16_t*)dresid, (bf16_t*)dx, workspace, M, D, q8);                                                \
+    else                                                                                                                               \
+    hipLaunchKernelGGL((ln_row_bwd_kernel<TT, NVV, RR, false>), dim3(blocks), dim3(256), lds, s, (const TT*)dy, (const TT*)x, gamma, mean, rstd, \
                        (const TT*)dresid, (TT*)dx, workspace, M, D, q8)
 #define LN_BWD_NV(TT, RR)                                                     \
     do {                                                                      \
@@ -414,13 +428,13 @@ __global__ __launch_bounds__(64) void chw_finalize_kernel(const float* __restric
 
 // SUMS: `stats` holds the per-sample (sum, sum of squares) produced by the convolution's epilogue; mean / rstd are derived here
 // (and written to stats_out for the backward pass) instead of by two more passes over x.
-template <typename T, bool SUMS = false>
+template <typename T, bool SUMS = false, bool Q8 = false>
 __global__ __launch_bounds__(256) void chw_apply_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ stats,
                                                         T* __restrict__ y, int64_t E, int b, int ngroups, float* __restrict__ stats_out = nullptr,
                                                         float eps = 0.f, const theia_q8_out_t q8 = {nullptr, nullptr, nullptr}) {
-    const float qsc = q8.out != nullptr ? *q8.scale : 0.f;
-    float qam = 0.f;
+    float qsc = 0.f, qam = 0.f;
+    if constexpr (Q8) qsc = *q8.scale;
     // a block owns 2048 elements of the affine row (f32 gamma / beta: 8 B per element, in registers) and walks over its group of
     // samples -- the round-2 kernel (one block per sample) re-read those 8 B for every 2 B of x
     const int grp = blockIdx.y;
@@ -456,9 +470,9 @@ __global__ __launch_bounds__(256) void chw_apply_kernel(const T* __restrict__ x,
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (xv[j] - mu) * rs * g8[j] + b8[j];
         store8(y + (int64_t)sample * E + e, o);
-        if (q8.out != nullptr) q8_store8(q8.out, (int64_t)sample * E + e, o, qsc, qam);
+        if constexpr (Q8) q8_store8(q8.out, (int64_t)sample * E + e, o, qsc, qam);
     }
-    if (q8.out != nullptr) q8_flush_wave(q8.amax, qam);
+    if constexpr (Q8) q8_flush_wave(q8.amax, qam);
 }
 
 extern "C" int theia_layernorm_chw_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
@@ -496,8 +510,10 @@ extern "C" int theia_layernorm_chw_fwd_sums(const void* x, const float* gamma, c
     const int64_t colb = (E / 8 + 255) / 256;
     const int ng = chw_sample_groups(b, colb);
     const dim3 grid((unsigned)colb, ng);
-    if (dtype == THEIA_BF16)
-        hipLaunchKernelGGL((chw_apply_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, sums, (bf16_t*)y, E, b, ng, stats, eps, q8);
+    if (dtype == THEIA_BF16 && q8.out != nullptr)
+        hipLaunchKernelGGL((chw_apply_kernel<bf16_t, true, true>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, sums, (bf16_t*)y, E, b, ng, stats, eps, q8);
+    else if (dtype == THEIA_BF16)
+        hipLaunchKernelGGL((chw_apply_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, sums, (bf16_t*)y, E, b, ng, stats, eps);
     else
         hipLaunchKernelGGL((chw_apply_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, gamma, beta, sums, (float*)y, E, b, ng, stats, eps);
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_fwd_sums");
@@ -512,22 +528,27 @@ extern "C" int theia_layernorm_chw_fwd_sums_q8(const void* x, const float* gamma
 // dx for a group of samples + partial affine gradients of that group
 // DXSUM: also the group's sum over samples of dx per element (part3[grp][E]) -- the producing convolution's bias gradient is its
 // sum over pixels, so the 805 MB re-read of dx by a column-sum kernel (64x64 maps) becomes a 12.6 MB one
-template <typename T, bool DXSUM>
+template <typename T, bool DXSUM, bool Q8 = false>
 __global__ __launch_bounds__(256) void chw_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                       const float* __restrict__ gamma, const float* __restrict__ stats,
                                                       const float* __restrict__ dstat, T* __restrict__ dx,
                                                       float* __restrict__ part, float* __restrict__ part3, int b, int64_t E, int ngroups,
                                                       int relu_mask, const theia_q8_out_t q8) {
+    // (Q8: a separate instantiation, see ln_row_fwd_kernel; every lane of a wave must reach the reduction of the maxima, so that form
+    // has no early return)
     const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    const float qsc = q8.out != nullptr ? *q8.scale : 0.f;
-    float qam = 0.f;
-    if (e < E) {  // (no early return: every lane of the wave reaches the reduction of the maxima below)
+    float qsc = 0.f, qam = 0.f;
+    if constexpr (Q8) qsc = *q8.scale;
+    if constexpr (!Q8) {
+        if (e >= E) return;
+    }
+    if (!Q8 || e < E) {
         const int grp = blockIdx.y;
         const int per = (b + ngroups - 1) / ngroups;
         const int s0 = grp * per, s1 = min(b, s0 + per);
         float g8[8], ag[8], ab[8], ac[8];
         load8(gamma + e, g8);
-    #pragma unroll
+#pragma unroll
         for (int j = 0; j < 8; ++j) ag[j] = ab[j] = ac[j] = 0.f;
         for (int s = s0; s < s1; ++s) {
             const float mu = stats[2 * s], rs = stats[2 * s + 1];
@@ -535,7 +556,7 @@ __global__ __launch_bounds__(256) void chw_bwd_kernel(const T* __restrict__ dy, 
             float xv[8], dv[8], o[8];
             load8(x + (int64_t)s * E + e, xv);
             load8(dy + (int64_t)s * E + e, dv);
-    #pragma unroll
+#pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float xh = (xv[j] - mu) * rs;
                 ag[j] += dv[j] * xh;
@@ -545,9 +566,9 @@ __global__ __launch_bounds__(256) void chw_bwd_kernel(const T* __restrict__ dy, 
                 o[j] = d;
             }
             store8(dx + (int64_t)s * E + e, o);
-            if (q8.out != nullptr) q8_store8(q8.out, (int64_t)s * E + e, o, qsc, qam);
+            if constexpr (Q8) q8_store8(q8.out, (int64_t)s * E + e, o, qsc, qam);
             if constexpr (DXSUM) {
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < 8; ++j) ac[j] += sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(o[j])) : o[j];  // the value as stored
             }
         }
@@ -556,7 +577,7 @@ __global__ __launch_bounds__(256) void chw_bwd_kernel(const T* __restrict__ dy, 
         store8(pg + E + e, ab);
         if constexpr (DXSUM) store8(part3 + (int64_t)grp * E + e, ac);
     }
-    if (q8.out != nullptr) q8_flush_wave(q8.amax, qam);
+    if constexpr (Q8) q8_flush_wave(q8.amax, qam);
 }
 
 extern "C" int theia_layernorm_chw_bwd_colsum(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
@@ -599,7 +620,10 @@ extern "C" int theia_layernorm_chw_bwd_colsum(const void* dy, const void* x, con
     hipLaunchKernelGGL(chw_finalize_kernel<1>, dim3(b), dim3(64), 0, s, part_stats, dstat, b, nch, E, 0.f);
     THEIA_CHECK_LAUNCH("theia_layernorm_chw_bwd(finalize)");
     const dim3 grid((unsigned)((E / 8 + 255) / 256), ng);
-    if (dtype == THEIA_BF16) {
+    if (dtype == THEIA_BF16 && q8.out != nullptr) {
+        if (dxsum) hipLaunchKernelGGL((chw_bwd_kernel<bf16_t, true, true>), grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, stats, dstat, (bf16_t*)dx, parts, parts3, b, E, ng, relu_mask, q8);
+        else hipLaunchKernelGGL((chw_bwd_kernel<bf16_t, false, true>), grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, stats, dstat, (bf16_t*)dx, parts, parts3, b, E, ng, relu_mask, q8);
+    } else if (dtype == THEIA_BF16) {
         if (dxsum) hipLaunchKernelGGL((chw_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, stats, dstat, (bf16_t*)dx, parts, parts3, b, E, ng, relu_mask, q8);
         else hipLaunchKernelGGL((chw_bwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, stats, dstat, (bf16_t*)dx, parts, parts3, b, E, ng, relu_mask, q8);
     } else {
