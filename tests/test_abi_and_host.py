@@ -29,6 +29,21 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert lib.theia_dtype_size(N.F32) == 4 and lib.theia_dtype_size(N.BF16) == 2 and lib.theia_dtype_size(7) == -1
 
 
+def test_quantize_batch_plan_and_group_split_count_are_host_logic():
+    """theia_quantize_fp8_batch_plan (ABI v11): block prefix sums of a host job table, bad tables refused; theia_wgrad_group_splits: CUs / tiles"""
+    from theia_amd import _native as N
+    lib = N.lib()
+    jobs = (N.QuantJob * 3)()
+    for j, n in zip(jobs, (8192, 8200, 64)):
+        j.src, j.dst, j.scale, j.n = 1024, 2048, 4096, n
+    assert lib.theia_quantize_fp8_batch_plan(C.addressof(jobs), 3) == 1 + 2 + 1
+    assert [j.first_block for j in jobs] == [0, 1, 3]
+    jobs[1].n = 12  # not a multiple of 8
+    assert lib.theia_quantize_fp8_batch_plan(C.addressof(jobs), 3) < 0
+    cus = lib.theia_get_compute_cus()
+    assert lib.theia_wgrad_group_splits(25216, 36) == cus // 36 and lib.theia_wgrad_group_splits(64, 1) == 1
+
+
 def test_gemm_schedule_switch_is_host_state():
     """theia_set_gemm_schedule / theia_get_gemm_schedule (ABI v10): host-side state of the persistent NT GEMM's tile schedule, static by
     default, returns the previous setting (no launch involved)."""
@@ -47,7 +62,7 @@ def test_struct_layout_matches_header(tmp_path):
     from theia_amd import _native as N
     probes = [("theia_rowmap_t", N.RowMap, "in_batch_stride"), ("theia_gemm_args_t", N.GemmArgs, "tile"),
               ("theia_gemm_args_t", N.GemmArgs, "w_scale_inv"), ("theia_gemm_args_t", N.GemmArgs, "out8_scale"), ("theia_wgrad_args_t", N.WgradArgs, "defer_bias_reduce"),
-              ("theia_cast_job_t", N.CastJob, "first_block")]
+              ("theia_cast_job_t", N.CastJob, "first_block"), ("theia_quant_job_t", N.QuantJob, "first_block"), ("theia_q8_out_t", N.Q8Out, "amax")]
     src = "#include <stdio.h>\n#include <stddef.h>\n#include \"theia_hip.h\"\nint main(void){\n"
     for cname, _, field in probes:
         src += f'printf("%zu %zu\\n", sizeof({cname}), offsetof({cname}, {field}));\n'
