@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define THEIA_ABI_VERSION 11
+#define THEIA_ABI_VERSION 12
 
 enum { THEIA_OK = 0, THEIA_ERR_INVALID = -1, THEIA_ERR_LAUNCH = -2, THEIA_ERR_UNSUPPORTED = -3 };
 enum { THEIA_F32 = 0, THEIA_BF16 = 1,
@@ -220,6 +220,22 @@ int theia_wgrad_reduce(const float* slabs, int splits, int N, int kslots, int C,
 int theia_wgrad_finish(const float* slabs, int splits, int N, int kslots, int C, float* out, int64_t sn, int64_t ss, int64_t sc,
                        int accumulate, const float* bias_slabs, float* bias_out, int bias_accumulate, void* stream);
 
+/* v12: the reductions behind one theia_gemm_wgrad_group launch as ONE launch (the small students run a layer's four nn.Linear gradients
+ * as a group: 4 reductions of ~5 us each per layer were a tenth of the step's launches).  Each job is theia_wgrad_finish(slabs, splits, N, 1, C,
+ * out, sn, 0, 1, accumulate, bias_slabs, bias_out, bias_accumulate): same summation order, bit-identical results.  THEIA_ERR_UNSUPPORTED
+ * (nothing launched) when a job does not have the nn.Linear form that function's 16-byte path takes, or n > THEIA_WGRAD_FINISH_GROUP_MAX. */
+#define THEIA_WGRAD_FINISH_GROUP_MAX 4
+typedef struct {
+    const float* slabs;
+    float* out;
+    const float* bias_slabs; /* NULL together with bias_out */
+    float* bias_out;
+    int64_t sn;              /* elements between output rows */
+    int32_t N, C;
+    int32_t accumulate, bias_accumulate;
+} theia_wgrad_finish_job_t;
+int theia_wgrad_finish_group(const theia_wgrad_finish_job_t* jobs, int n, int splits, void* stream);
+
 /* out[n] (+)= sum_m x[m*ld + n]   (bias gradients; x has `dtype` elements, out f32)  */
 int theia_colsum(const void* x, int64_t M, int N, int64_t ld, float* out, float* workspace, int accumulate,
                  int dtype, void* stream);
@@ -293,6 +309,9 @@ int theia_unpermute3_f32(const float* src, float* dst, int d0, int d1, int d2, i
 
 /* dst[c*R + r] (+)= src[r*C + c]  (f32 transpose, both sides coalesced: LayerNorm[C,H,W] affine gradients [HW][C] -> [C][HW]) */
 int theia_transpose_acc_f32(const float* src, float* dst, int R, int C, int accumulate, void* stream);
+/* v12: two matrices of one shape by one launch (a LayerNorm[C,H,W]'s weight and bias gradients, adapter_heads.py:306-324 under autograd) */
+int theia_transpose_acc2_f32(const float* src0, float* dst0, int accumulate0, const float* src1, float* dst1, int accumulate1, int R, int C,
+                             void* stream);
 
 /* Image resize of the reference's HF image processor (models/backbones.py:337-339 -> Pillow Image.resize, two-pass 8-bit
  * resampling, Pillow 12.2.0 src/libImaging/Resample.c): src uint8 [b, in_h, in_w, 3] (channels_last) or [b, 3, in_h, in_w]

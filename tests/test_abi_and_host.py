@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/theia_hip.h but not exported"
     assert sorted(N.EXPORTED_SYMBOLS) == declared, "ctypes signature table and header disagree"
-    assert lib.theia_abi_version() == N.ABI_VERSION == 11
+    assert lib.theia_abi_version() == N.ABI_VERSION == 12
     assert lib.theia_dtype_size(N.F32) == 4 and lib.theia_dtype_size(N.BF16) == 2 and lib.theia_dtype_size(7) == -1
 
 
@@ -62,7 +62,8 @@ def test_struct_layout_matches_header(tmp_path):
     from theia_amd import _native as N
     probes = [("theia_rowmap_t", N.RowMap, "in_batch_stride"), ("theia_gemm_args_t", N.GemmArgs, "tile"),
               ("theia_gemm_args_t", N.GemmArgs, "w_scale_inv"), ("theia_gemm_args_t", N.GemmArgs, "out8_scale"), ("theia_wgrad_args_t", N.WgradArgs, "defer_bias_reduce"),
-              ("theia_cast_job_t", N.CastJob, "first_block"), ("theia_quant_job_t", N.QuantJob, "first_block"), ("theia_q8_out_t", N.Q8Out, "amax")]
+              ("theia_cast_job_t", N.CastJob, "first_block"), ("theia_quant_job_t", N.QuantJob, "first_block"), ("theia_q8_out_t", N.Q8Out, "amax"),
+              ("theia_wgrad_finish_job_t", N.WgradFinishJob, "bias_accumulate")]
     src = "#include <stdio.h>\n#include <stddef.h>\n#include \"theia_hip.h\"\nint main(void){\n"
     for cname, _, field in probes:
         src += f'printf("%zu %zu\\n", sizeof({cname}), offsetof({cname}, {field}));\n'

@@ -54,7 +54,7 @@ def rnd(x, dt):
 def test_library_loads_and_abi():
     from theia_amd import _native as N
     lib = N.lib()
-    assert lib.theia_abi_version() == N.ABI_VERSION == 11
+    assert lib.theia_abi_version() == N.ABI_VERSION == 12
     assert lib.theia_dtype_size(N.BF16) == 2
 
 
@@ -235,6 +235,59 @@ def test_grouped_linear_wgrad_matches_the_single_launches(dt, M, D):
         ops.linear_wgrad(dy, x, g1, acc, bias=(b1, acc))
         assert relerr(gw, g1) < (1e-6 if dt == torch.float32 else 2e-4)  # same products, another split of the f32 row sums
         assert relerr(gb, b1) < 1e-6
+
+
+def test_grouped_wgrad_finish_is_bit_identical_to_the_single_reductions():
+    """theia_wgrad_finish_group (ABI v12): the slab reductions behind one grouped weight-gradient launch as ONE launch -- the same sums in the
+    same order as theia_wgrad_finish per problem (bitwise), accumulate on / off per job, bias partials included; a job outside the
+    16-byte path is refused without launching anything; theia_transpose_acc2_f32 against two theia_transpose_acc_f32."""
+    import ctypes
+    from theia_amd import ops, _native as Nn
+    dev = _dev()
+    torch.manual_seed(5)
+    splits = 7
+    shapes = [(576, 192), (192, 192), (768, 192), (192, 768)]
+    jobs = (Nn.WgradFinishJob * len(shapes))()
+    keep, outs = [], []
+    for i, (n, c) in enumerate(shapes):
+        slabs, bsl = torch.randn(splits, n, c, device=dev), torch.randn(splits, n, device=dev)
+        acc = bool(i & 1)
+        gw, gb = torch.randn(n, c, device=dev), torch.randn(n, device=dev)
+        w1, b1 = gw.clone(), gb.clone()
+        ops.wgrad_finish(slabs, splits, n, 1, c, w1, c, 0, 1, acc, (bsl, b1, not acc))
+        jobs[i] = Nn.WgradFinishJob(slabs.data_ptr(), gw.data_ptr(), bsl.data_ptr(), gb.data_ptr(), c, n, c, int(acc), int(not acc))
+        keep.append((slabs, bsl))
+        outs.append((gw, gb, w1, b1))
+    assert Nn.lib().theia_wgrad_finish_group(jobs, len(shapes), splits, Nn.stream_ptr()) == 0
+    for gw, gb, w1, b1 in outs:
+        assert torch.equal(gw, w1) and torch.equal(gb, b1)
+    # weights only (no bias pointers), 2 jobs
+    j2 = (Nn.WgradFinishJob * 2)()
+    o2 = []
+    for i, (n, c) in enumerate(shapes[:2]):
+        gw = torch.zeros(n, c, device=dev)
+        w1 = torch.zeros(n, c, device=dev)
+        ops.wgrad_finish(keep[i][0], splits, n, 1, c, w1, c, 0, 1, False)
+        j2[i] = Nn.WgradFinishJob(keep[i][0].data_ptr(), gw.data_ptr(), None, None, c, n, c, 0, 0)
+        o2.append((gw, w1))
+    assert Nn.lib().theia_wgrad_finish_group(j2, 2, splits, Nn.stream_ptr()) == 0
+    for gw, w1 in o2:
+        assert torch.equal(gw, w1)
+    # an output that is not 16-byte aligned: refused, nothing written
+    base = torch.zeros(192 * 192 + 1, device=dev)
+    j2[1] = Nn.WgradFinishJob(keep[1][0].data_ptr(), base[1:].data_ptr(), None, None, 192, 192, 192, 0, 0)
+    assert Nn.lib().theia_wgrad_finish_group(j2, 2, splits, Nn.stream_ptr()) == Nn.ERR_UNSUPPORTED
+    assert float(base.abs().sum()) == 0.0
+    assert Nn.lib().theia_wgrad_finish_group(j2, 5, splits, Nn.stream_ptr()) == Nn.ERR_UNSUPPORTED
+    # paired transpose
+    R, Cc = 196, 192
+    a, b_ = torch.randn(R, Cc, device=dev), torch.randn(R, Cc, device=dev)
+    d0, d1 = torch.randn(Cc, R, device=dev), torch.randn(Cc, R, device=dev)
+    e0, e1 = d0.clone(), d1.clone()
+    ops.transpose_acc(a, e0, R, Cc, True)
+    ops.transpose_acc(b_, e1, R, Cc, False)
+    ops.transpose_acc2(a, d0, True, b_, d1, False, R, Cc)
+    assert torch.equal(d0, e0) and torch.equal(d1, e1) and torch.equal(d1, b_.t())
 
 
 def _nhwc(a):
@@ -583,10 +636,10 @@ def test_bench_size_linears_run_the_pingpong_kernel(M, N, K, kind):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("D", [192, 384, 768])
-def test_layernorm_rows(dt, D):
+@pytest.mark.parametrize("M", [197 * 3 + 1, 197 * 3])  # odd M: the two-rows-per-wave kernels (D <= 256) have a last row without a partner
+def test_layernorm_rows(dt, D, M):
     from theia_amd import ops
     dev = _dev()
-    M = 197 * 3 + 1
     x = h((M, D), 41, 2.0) + 0.3
     g = h((D,), 42, 0.2) + 1.0
     bta = h((D,), 43, 0.2)
@@ -605,6 +658,77 @@ def test_layernorm_rows(dt, D):
     assert relerr(dx.float(), xr.grad + rnd(dres, dt)) < (1e-4 if dt == torch.float32 else 2e-2)
     assert relerr(dg, gr.grad) < 1e-4
     assert relerr(db, br.grad) < 1e-4
+    x64 = rnd(x, dt).double()
+    assert relerr(mean, x64.mean(1)) < 1e-5 and relerr(rstd, 1.0 / torch.sqrt(x64.var(1, unbiased=False) + 1e-12)) < 1e-4
+    # without a residual-stream gradient, accumulating into the affine gradients
+    dx0 = ops.layernorm_bwd(dy.to(dev, dt), x.to(dev, dt), g.to(dev), mean, rstd, None, dg, db, accumulate=True)
+    assert relerr(dx0.float(), xr.grad) < (1e-4 if dt == torch.float32 else 2e-2)
+    assert relerr(dg, 2 * gr.grad) < 1e-4 and relerr(db, 2 * br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("D", [192, 384, 768])
+def test_fused_e4m3_side_outputs_equal_the_quantised_bf16_outputs(D):
+    """The *_q8 entry points (ABI v11): a pass's e4m3 copy of its main output must be, byte for byte, theia_quantize_fp8 of the bf16 output it
+    stores beside it (same scale), the bf16 output itself must not change, and a given amax slot ends at max(amax, max |output|).
+    Row LayerNorm forward / backward (one- and two-rows-per-wave kernels), LayerNorm[C,H,W] one-pass forward and backward, loss gradient."""
+    from theia_amd import ops
+    dev = _dev()
+    dt = torch.bfloat16
+    M = 197 * 3
+    sc = torch.tensor([3.0], device=dev)
+
+    def check(y, y8, amax, plain):
+        # (the side-output forms are separate instantiations: the compiler may contract their f32 expressions differently -- a bf16 ulp)
+        assert relerr(y.float(), plain.float()) < 1e-2 and float((y != plain).float().mean()) < 0.01
+        want = ops.quantize_fp8(y.view(-1, y.shape[-1]), sc)
+        assert torch.equal(y8.view(torch.uint8).view(-1), want.view(torch.uint8).view(-1))
+        if amax is not None:
+            assert float(amax) == max(0.125, float(y.float().abs().max()))
+
+    x, g, bta = h((M, D), 41, 2.0).to(dev, dt), (h((D,), 42, 0.2) + 1.0).to(dev), h((D,), 43, 0.2).to(dev)
+    for with_amax in (True, False):
+        am = torch.tensor([0.125], device=dev) if with_amax else None
+        y8 = torch.empty(M, D, dtype=torch.float8_e4m3fn, device=dev)
+        y, mean, rstd = ops.layernorm_fwd(x, g, bta, 1e-12, q8=(y8, sc, am))
+        check(y, y8, am, ops.layernorm_fwd(x, g, bta, 1e-12)[0])
+        dy, dres = h((M, D), 44, 1.0).to(dev, dt), h((M, D), 45, 1.0).to(dev, dt)
+        for res in (dres, None):
+            am = torch.tensor([0.125], device=dev) if with_amax else None
+            dg, db, dg0, db0 = (torch.zeros(D, device=dev) for _ in range(4))
+            d8 = torch.empty(M, D, dtype=torch.float8_e4m3fn, device=dev)
+            dx = ops.layernorm_bwd(dy, x, g, mean, rstd, res, dg, db, accumulate=False, q8=(d8, sc, am))
+            check(dx, d8, am, ops.layernorm_bwd(dy, x, g, mean, rstd, res, dg0, db0, accumulate=False))
+            assert relerr(dg, dg0) < 1e-5 and relerr(db, db0) < 1e-5
+    # LayerNorm[C,H,W]: the one-pass forward (statistics from the producer's fixed-point sums) and the backward
+    b, H, C = 5, 16, D // 3
+    E = H * H * C
+    xc = torch.relu(h((b, E), 51, 2.0) + 0.2).to(dev, dt)
+    gc, sc_ = (h((E,), 52, 0.2) + 1.0).to(dev), h((E,), 53, 0.2).to(dev)
+    x64 = xc.double()
+    sums = torch.stack([(x64.sum(1) * 2 ** 24).round(), ((x64 * x64).sum(1) * 2 ** 24).round()], 1).to(torch.int64).contiguous()
+    am = torch.tensor([0.125], device=dev)
+    y8 = torch.empty(b, E, dtype=torch.float8_e4m3fn, device=dev)
+    y, stats = ops.layernorm_chw_fwd(xc, gc, sc_, 1e-5, sums=sums, q8=(y8, sc, am))
+    check(y, y8, am, ops.layernorm_chw_fwd(xc, gc, sc_, 1e-5, sums=sums)[0])
+    dyc = h((b, E), 54, 1.0).to(dev, dt)
+    for mask in (False, True):
+        am = torch.tensor([0.125], device=dev)
+        dg, ds, dg0, ds0 = (torch.zeros(E, device=dev) for _ in range(4))
+        d8 = torch.empty(b, E, dtype=torch.float8_e4m3fn, device=dev)
+        dx = ops.layernorm_chw_bwd(dyc, xc, gc, stats, dg, ds, relu_mask=mask, accumulate=False, q8=(d8, sc, am))
+        check(dx, d8, am, ops.layernorm_chw_bwd(dyc, xc, gc, stats, dg0, ds0, relu_mask=mask, accumulate=False))
+        assert relerr(dg, dg0) < 1e-5 and relerr(ds, ds0) < 1e-5
+    # loss gradient
+    pred, tgt = h((b, E), 61, 1.0).to(dev, dt), h((b, E), 62, 1.0).to(dev, dt)
+    _, coef = ops.distill_loss_fwd(pred, tgt)
+    w = torch.tensor([0.2, 0.9, 0.1], device=dev)
+    sc.fill_(2.0 ** 12)  # (loss gradients are ~1 / (b E))
+    am = torch.tensor([0.0], device=dev)
+    d8 = torch.empty(b, E, dtype=torch.float8_e4m3fn, device=dev)
+    dp = ops.distill_loss_bwd(pred, tgt, coef, w, q8=(d8, sc, am))
+    plain = ops.distill_loss_bwd(pred, tgt, coef, w)
+    assert relerr(dp.float(), plain.float()) < 1e-2 and float(am) == float(dp.float().abs().max())
+    assert torch.equal(d8.view(torch.uint8), ops.quantize_fp8(dp, sc).view(torch.uint8))
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

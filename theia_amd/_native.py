@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtheia_hip.so")
 
 F32, BF16, FP8 = 0, 1, 2
 ERR_UNSUPPORTED = -3  # THEIA_ERR_UNSUPPORTED
-ABI_VERSION = 11
+ABI_VERSION = 12
 COMM_ID_BYTES = 128  # THEIA_COMM_ID_BYTES
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_MUL_DGELU, ACT_MUL_DRELU = 0, 1, 2, 3, 4
 MAX_TAPS = 9
@@ -73,6 +73,15 @@ class QuantJob(C.Structure):  # theia_quant_job_t
                 ("first_block", C.c_int32), ("pad_", C.c_int32)]
 
 
+class WgradFinishJob(C.Structure):
+    """theia_wgrad_finish_job_t"""
+    _fields_ = [("slabs", C.c_void_p), ("out", C.c_void_p), ("bias_slabs", C.c_void_p), ("bias_out", C.c_void_p), ("sn", C.c_int64),
+                ("N", C.c_int32), ("C", C.c_int32), ("accumulate", C.c_int32), ("bias_accumulate", C.c_int32)]
+
+
+WGRAD_FINISH_GROUP_MAX = 4
+
+
 class WgradArgs(C.Structure):
     _fields_ = [
         ("dy", C.c_void_p), ("a", C.c_void_p), ("slabs", C.c_void_p),
@@ -106,6 +115,7 @@ _SIGNATURES = {
                                      C.c_int64, C.c_int, C.c_void_p]),
     "theia_wgrad_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "theia_wgrad_finish_group": (C.c_int, [C.POINTER(WgradFinishJob), C.c_int, C.c_int, C.c_void_p]),
     "theia_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "theia_quantize_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "theia_fp8_update_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
@@ -127,6 +137,7 @@ _SIGNATURES = {
     "theia_unpermute3_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64,
                                        C.c_int, C.c_void_p]),
     "theia_transpose_acc_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "theia_transpose_acc2_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "theia_patchify_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "theia_patchify_u8_hw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "theia_write_cls": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -857,11 +857,11 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
 
 // nn.Linear gradients (one slot, channels contiguous in the output: slab order IS output order): a plain 16-byte reduction, no LDS.
 // 48 of the 69 finish launches of a DeiT-base step; the tiled kernel above spent them on 2-element-per-thread blocks.
-__global__ __launch_bounds__(256) void wgrad_finish_rows_kernel(const float* __restrict__ slabs, int splits, int N, int C, float* __restrict__ out,
-                                                                int64_t sn, int accumulate, int wblocks, const float* __restrict__ bias_part,
-                                                                float* __restrict__ bias_out, int bias_accumulate) {
-    if ((int)blockIdx.x >= wblocks) {
-        const int n = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
+__device__ __forceinline__ void wf_rows_body(int bid, const float* __restrict__ slabs, int splits, int N, int C, float* __restrict__ out, int64_t sn,
+                                             int accumulate, int wblocks, const float* __restrict__ bias_part, float* __restrict__ bias_out,
+                                             int bias_accumulate) {
+    if (bid >= wblocks) {
+        const int n = (bid - wblocks) * 256 + threadIdx.x;
         if (n < N) {
             const float s = wf_sum1(bias_part + n, N, 0, splits, 0.f);
             bias_out[n] = bias_accumulate ? bias_out[n] + s : s;
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_rows_kernel(const float* __r
     const int c4n = C >> 2;
     const int64_t total4 = (int64_t)N * c4n, total = (int64_t)N * C;
     const float rcp = 1.0f / (float)c4n;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)wblocks * 256) {
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < total4; i += (int64_t)wblocks * 256) {
         float4 s = *reinterpret_cast<const float4*>(slabs + i * 4);
         s = wf_sum4(slabs + i * 4, total, 1, splits, s);
         int c4;
@@ -885,6 +885,64 @@ __global__ __launch_bounds__(256) void wgrad_finish_rows_kernel(const float* __r
     }
 }
 
+__global__ __launch_bounds__(256) void wgrad_finish_rows_kernel(const float* __restrict__ slabs, int splits, int N, int C, float* __restrict__ out,
+                                                                int64_t sn, int accumulate, int wblocks, const float* __restrict__ bias_part,
+                                                                float* __restrict__ bias_out, int bias_accumulate) {
+    wf_rows_body((int)blockIdx.x, slabs, splits, N, C, out, sn, accumulate, wblocks, bias_part, bias_out, bias_accumulate);
+}
+
+// the reductions behind ONE grouped weight-gradient launch (theia_gemm_wgrad_group) as one launch: block ranges, one per problem
+struct wf_group_t {
+    int njobs, splits;
+    int first[THEIA_WGRAD_FINISH_GROUP_MAX + 1];   // first[j] .. first[j + 1]: job j's blocks (its weight blocks, then its bias blocks)
+    int wblocks[THEIA_WGRAD_FINISH_GROUP_MAX];
+    theia_wgrad_finish_job_t job[THEIA_WGRAD_FINISH_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void wgrad_finish_rows_group_kernel(const wf_group_t g) {
+    const int bid = (int)blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < THEIA_WGRAD_FINISH_GROUP_MAX; ++q)
+        if (q < g.njobs && bid >= g.first[q]) j = q;
+    const theia_wgrad_finish_job_t& t = g.job[j];
+    wf_rows_body(bid - g.first[j], t.slabs, g.splits, t.N, t.C, t.out, t.sn, t.accumulate, g.wblocks[j], t.bias_slabs, t.bias_out, t.bias_accumulate);
+}
+
+static bool wf_rows_ok(const float* slabs, const float* out, int N, int C, int64_t sn) {
+    return (C & 3) == 0 && (sn & 3) == 0 && (int64_t)N * (C >> 2) < ((int64_t)1 << 24) &&
+           ((reinterpret_cast<uint64_t>(slabs) | reinterpret_cast<uint64_t>(out)) & 15) == 0;
+}
+static int wf_rows_blocks(int N, int C) {
+    int wblocks = (int)(((int64_t)N * (C >> 2) + 255) / 256);
+    return wblocks > 4096 ? 4096 : wblocks;
+}
+
+extern "C" int theia_wgrad_finish_group(const theia_wgrad_finish_job_t* jobs, int n, int splits, void* stream) {
+    THEIA_CHECK_ARG(jobs && n >= 1 && splits >= 1, "theia_wgrad_finish_group: bad args");
+    if (n > THEIA_WGRAD_FINISH_GROUP_MAX) return THEIA_ERR_UNSUPPORTED;
+    wf_group_t g;
+    g.njobs = n;
+    g.splits = splits;
+    g.first[0] = 0;
+    for (int j = 0; j < n; ++j) {
+        const theia_wgrad_finish_job_t& t = jobs[j];
+        THEIA_CHECK_ARG(t.slabs && t.out && t.N > 0 && t.C > 0, "theia_wgrad_finish_group: bad job");
+        THEIA_CHECK_ARG((t.bias_out == nullptr) == (t.bias_slabs == nullptr), "theia_wgrad_finish_group: bias_slabs and bias_out go together");
+        if (!wf_rows_ok(t.slabs, t.out, t.N, t.C, t.sn)) return THEIA_ERR_UNSUPPORTED;
+        g.job[j] = t;
+        g.wblocks[j] = wf_rows_blocks(t.N, t.C);
+        g.first[j + 1] = g.first[j] + g.wblocks[j] + (t.bias_out != nullptr ? cdiv_i(t.N, 256) : 0);
+    }
+    for (int j = n; j < THEIA_WGRAD_FINISH_GROUP_MAX; ++j) {
+        g.job[j] = g.job[0];
+        g.wblocks[j] = 0;
+        g.first[j + 1] = g.first[n];
+    }
+    hipLaunchKernelGGL(wgrad_finish_rows_group_kernel, dim3(g.first[n]), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g);
+    THEIA_CHECK_LAUNCH("theia_wgrad_finish_group");
+    return THEIA_OK;
+}
+
 extern "C" int theia_wgrad_finish(const float* slabs, int splits, int N, int kslots, int C, float* out, int64_t sn, int64_t ss,
                                   int64_t sc, int accumulate, const float* bias_slabs, float* bias_out, int bias_accumulate,
                                   void* stream) {
@@ -892,10 +950,8 @@ extern "C" int theia_wgrad_finish(const float* slabs, int splits, int N, int ksl
     THEIA_CHECK_ARG((bias_out == nullptr) == (bias_slabs == nullptr), "theia_wgrad_finish: bias_slabs and bias_out go together");
     const int btiles = bias_out != nullptr ? cdiv_i(N, 256) : 0;
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-    if (kslots == 1 && sc == 1 && (C & 3) == 0 && (sn & 3) == 0 && (int64_t)N * (C >> 2) < ((int64_t)1 << 24) &&
-        ((reinterpret_cast<uint64_t>(slabs) | reinterpret_cast<uint64_t>(out)) & 15) == 0) {
-        int wblocks = (int)(((int64_t)N * (C >> 2) + 255) / 256);
-        if (wblocks > 4096) wblocks = 4096;
+    if (kslots == 1 && sc == 1 && wf_rows_ok(slabs, out, N, C, sn)) {
+        const int wblocks = wf_rows_blocks(N, C);
         hipLaunchKernelGGL(wgrad_finish_rows_kernel, dim3(wblocks + btiles), dim3(256), 0, hs, slabs, splits, N, C, out, sn, accumulate, wblocks,
                            bias_slabs, bias_out, bias_accumulate);
         THEIA_CHECK_LAUNCH("theia_wgrad_finish");

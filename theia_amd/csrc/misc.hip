@@ -500,8 +500,7 @@ extern "C" int theia_fp8_update_scales(float* amax, float* scale, float* inv_sca
 
 // dst[c*R + r] (+)= src[r*C + c]: f32 matrix transpose through a 32x33 LDS tile (both sides coalesced).  The LayerNorm[C,H,W]
 // affine gradients are reduced in the NHWC order of the activations ([HW][C]) and live in the reference's [C][HW] order.
-__global__ __launch_bounds__(256) void transpose_acc_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C,
-                                                            int accumulate) {
+__device__ __forceinline__ void transpose_acc_tile(const float* __restrict__ src, float* __restrict__ dst, int R, int C, int accumulate) {
     __shared__ float t[32][33];
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -521,11 +520,29 @@ __global__ __launch_bounds__(256) void transpose_acc_kernel(const float* __restr
         }
     }
 }
+__global__ __launch_bounds__(256) void transpose_acc_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C,
+                                                            int accumulate) {
+    transpose_acc_tile(src, dst, R, C, accumulate);
+}
+// two matrices of one shape by one launch (blockIdx.z): a LayerNorm[C,H,W]'s weight and bias gradients
+__global__ __launch_bounds__(256) void transpose_acc2_kernel(const float* __restrict__ src0, float* __restrict__ dst0, int acc0,
+                                                             const float* __restrict__ src1, float* __restrict__ dst1, int acc1, int R, int C) {
+    if (blockIdx.z == 0) transpose_acc_tile(src0, dst0, R, C, acc0);
+    else transpose_acc_tile(src1, dst1, R, C, acc1);
+}
 extern "C" int theia_transpose_acc_f32(const float* src, float* dst, int R, int C, int accumulate, void* stream) {
     THEIA_CHECK_ARG(src && dst && R > 0 && C > 0, "theia_transpose_acc_f32: bad args");
     hipLaunchKernelGGL(transpose_acc_kernel, dim3(cdiv_i(C, 32), cdiv_i(R, 32)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, R,
                        C, accumulate);
     THEIA_CHECK_LAUNCH("theia_transpose_acc_f32");
+    return THEIA_OK;
+}
+extern "C" int theia_transpose_acc2_f32(const float* src0, float* dst0, int accumulate0, const float* src1, float* dst1, int accumulate1, int R,
+                                        int C, void* stream) {
+    THEIA_CHECK_ARG(src0 && dst0 && src1 && dst1 && R > 0 && C > 0, "theia_transpose_acc2_f32: bad args");
+    hipLaunchKernelGGL(transpose_acc2_kernel, dim3(cdiv_i(C, 32), cdiv_i(R, 32), 2), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src0,
+                       dst0, accumulate0, src1, dst1, accumulate1, R, C);
+    THEIA_CHECK_LAUNCH("theia_transpose_acc2_f32");
     return THEIA_OK;
 }
 

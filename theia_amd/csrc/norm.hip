@@ -88,6 +88,73 @@ __global__ __launch_bounds__(256) void ln_row_fwd_kernel(const T* __restrict__ x
     if constexpr (Q8) q8_flush_wave(q8.amax, qam);
 }
 
+// D <= 256 (DeiT-tiny: 24 of a wave's 64 lanes hold a vector of the row): TWO rows per wave, one per 32-lane half -- half the loads,
+// shuffles and stores per row; the sums run over the half's 32 lanes (another order of the same additions than the one-row form).
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <typename T, bool Q8>
+__global__ __launch_bounds__(256) void ln_row_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, T* __restrict__ y,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, int64_t M,
+                                                          int D, float eps, const theia_q8_out_t q8) {
+    const int lane = threadIdx.x & 63, l32 = lane & 31, half = lane >> 5;
+    float qsc = 0.f, qam = 0.f;
+    if constexpr (Q8) qsc = *q8.scale;
+    const int nv = D >> 3;
+    const float invD = 1.0f / (float)D;
+    const bool ok = l32 < nv;
+    const int vc = ok ? l32 : nv - 1;
+    float g8[8], b8[8];
+    bool first = true;
+    for (int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2; r0 < M; r0 += (int64_t)gridDim.x * 8) {
+        const bool rok = r0 + half < M;
+        const int64_t row = rok ? r0 + half : M - 1;  // (the odd last row's partner: loads from a clamped row, stores nothing)
+        float v[8];
+        load8(x + row * D + vc * 8, v);
+        if (first) {
+            load8(gamma + vc * 8, g8);
+            load8(beta + vc * 8, b8);
+            first = false;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += ok ? v[j] : 0.f;
+        const float mu = half_wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = v[j] - mu;
+            q += ok ? d * d : 0.f;
+        }
+        const float var = half_wave_sum(q) * invD;
+        const float rs = 1.0f / sqrtf(var + eps);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (v[j] - mu) * rs * g8[j] + b8[j];
+        if (ok && rok) store8(y + row * D + vc * 8, o);
+        if constexpr (Q8) {
+            if (ok && rok) q8_store8(q8.out, row * D + vc * 8, o, qsc, qam);
+        }
+        if (l32 == 0 && rok) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+    if constexpr (Q8) q8_flush_wave(q8.amax, qam);
+}
+static bool ln_two_rows(int D) {
+    static int on = -1;  // THEIA_LN_TWO_ROWS=0: the one-row-per-wave kernels for every D (A/B switch)
+    if (on < 0) {
+        const char* e = getenv("THEIA_LN_TWO_ROWS");
+        on = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    return on != 0 && D <= 256;
+}
+
 extern "C" int theia_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                                    float* rstd, int64_t M, int D, float eps, int dtype, void* stream) {
     THEIA_CHECK_ARG(x && gamma && beta && y && mean && rstd, "theia_layernorm_fwd: null pointer");
@@ -99,6 +166,19 @@ extern "C" int theia_layernorm_fwd(const void* x, const float* gamma, const floa
     // 8-element vectors per lane: 1 for D <= 512 (DeiT-small / -tiny: a second, fully masked vector would still be loaded -- the loads are
     // unconditional), 2 for D <= 1024, else LN_MAXV
     const int nvl = D <= 512 ? 1 : D <= 1024 ? 2 : LN_MAXV;
+    if (ln_two_rows(D)) {
+        int b2 = (int)((M + 7) / 8);
+        if (b2 > 8192) b2 = 8192;
+#define LN_FWD2_LAUNCH(TT, QQ) \
+    hipLaunchKernelGGL((ln_row_fwd2_kernel<TT, QQ>), dim3(b2), dim3(256), 0, s, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, M, D, eps, q8)
+        if (dtype == THEIA_BF16 && q8.out != nullptr) LN_FWD2_LAUNCH(bf16_t, true);
+        else if (dtype == THEIA_BF16) LN_FWD2_LAUNCH(bf16_t, false);
+        else if (dtype == THEIA_F32) LN_FWD2_LAUNCH(float, false);
+        else THEIA_CHECK_ARG(false, "theia_layernorm_fwd: bad dtype %d", dtype);
+#undef LN_FWD2_LAUNCH
+        THEIA_CHECK_LAUNCH("theia_layernorm_fwd");
+        return THEIA_OK;
+    }
 #define LN_FWD_LAUNCH(TT, NVV, QQ)                                                                                                            \
     hipLaunchKernelGGL((ln_row_fwd_kernel<TT, NVV, QQ>), dim3(blocks), dim3(256), 0, s, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, M, D, eps, q8)
     if (dtype == THEIA_BF16 && q8.out != nullptr) {
@@ -208,6 +288,77 @@ __global__ __launch_bounds__(256) void ln_row_bwd_kernel(const T* __restrict__ d
         part[(int64_t)blockIdx.x * 2 * D + i] = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
 }
 
+// two rows per wave for D <= 256 (see ln_row_fwd2_kernel); the affine partials of a block are the sum over its 8 half-waves
+template <typename T, bool HAS_RES, bool Q8>
+__global__ __launch_bounds__(256) void ln_row_bwd2_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                          T* __restrict__ dx, float* __restrict__ part, int64_t M, int D,
+                                                          const theia_q8_out_t q8) {
+    extern __shared__ float red[];  // [8][2*D]
+    float qsc = 0.f, qam = 0.f;
+    if constexpr (Q8) qsc = *q8.scale;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, half = lane >> 5;
+    const int nv = D >> 3;
+    const float invD = 1.0f / (float)D;
+    const bool ok = l32 < nv;
+    const int vc = ok ? l32 : nv - 1;
+    float ag[8], ab[8], g8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ag[j] = ab[j] = 0.f;
+    load8(gamma + vc * 8, g8);
+    for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 2; r0 < M; r0 += (int64_t)gridDim.x * 8) {
+        const bool rok = r0 + half < M, use = ok && rok;
+        const int64_t row = rok ? r0 + half : M - 1;
+        float xv[8], dv[8], rr[8];
+        load8(x + row * D + vc * 8, xv);
+        load8(dy + row * D + vc * 8, dv);
+        if constexpr (HAS_RES) load8(dres + row * D + vc * 8, rr);
+        const float mu = mean[row], rs = rstd[row];
+        __builtin_amdgcn_sched_barrier(0);
+        float xh[8], gy[8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            xh[j] = (xv[j] - mu) * rs;
+            gy[j] = dv[j] * g8[j];
+            s1 += ok ? gy[j] : 0.f;
+            s2 += ok ? gy[j] * xh[j] : 0.f;
+            ag[j] += use ? dv[j] * xh[j] : 0.f;
+            ab[j] += use ? dv[j] : 0.f;
+        }
+        const float m1 = half_wave_sum(s1) * invD, m2 = half_wave_sum(s2) * invD;
+        if constexpr (HAS_RES) asm volatile("" ::"v"(rr[0]));
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs * (gy[j] - m1 - xh[j] * m2);
+        if constexpr (HAS_RES) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += rr[j];
+        }
+        if (use) store8(dx + row * D + vc * 8, o);
+        if constexpr (Q8) {
+            if (use) q8_store8(q8.out, row * D + vc * 8, o, qsc, qam);
+        }
+    }
+    if constexpr (Q8) q8_flush_wave(q8.amax, qam);
+    float* mine = red + (wave * 2 + half) * 2 * D;
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mine[l32 * 8 + j] = ag[j];
+            mine[D + l32 * 8 + j] = ab[j];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        float t = red[i];
+#pragma unroll
+        for (int h = 1; h < 8; ++h) t += red[h * 2 * D + i];
+        part[(int64_t)blockIdx.x * 2 * D + i] = t;
+    }
+}
+
 // out[c] (+)= sum_p part[p][c]  for c in [0, ncol); deterministic order.
 // COLS columns x (256 / COLS) part lanes per block: a thread-per-column loop over hundreds of partial rows is latency-bound,
 // so the row-LN reduction (512 partial rows, 1536 columns) uses 16 x 16 (96 blocks, 32 loads per thread: 24 -> ~8 us) and the
@@ -267,6 +418,26 @@ extern "C" int theia_layernorm_bwd(const void* dy, const void* x, const float* g
     const bool res = dresid != nullptr;
     const theia_q8_out_t q8 = q8_take();
     const int nvl = D <= 512 ? 1 : D <= 1024 ? 2 : LN_MAXV;  // (see theia_layernorm_fwd)
+    if (ln_two_rows(D)) {
+        const size_t lds2 = 8 * 2 * D * sizeof(float);
+#define LN_BWD2_LAUNCH(TT, RR, QQ)                                                                                                              \
+    hipLaunchKernelGGL((ln_row_bwd2_kernel<TT, RR, QQ>), dim3(blocks), dim3(256), lds2, s, (const TT*)dy, (const TT*)x, gamma, mean, rstd, \
+                       (const TT*)dresid, (TT*)dx, workspace, M, D, q8)
+        if (dtype == THEIA_BF16 && q8.out != nullptr) {
+            if (res) LN_BWD2_LAUNCH(bf16_t, true, true); else LN_BWD2_LAUNCH(bf16_t, false, true);
+        } else if (dtype == THEIA_BF16) {
+            if (res) LN_BWD2_LAUNCH(bf16_t, true, false); else LN_BWD2_LAUNCH(bf16_t, false, false);
+        } else if (dtype == THEIA_F32) {
+            if (res) LN_BWD2_LAUNCH(float, true, false); else LN_BWD2_LAUNCH(float, false, false);
+        } else
+            THEIA_CHECK_ARG(false, "theia_layernorm_bwd: bad dtype %d", dtype);
+#undef LN_BWD2_LAUNCH
+        THEIA_CHECK_LAUNCH("theia_layernorm_bwd");
+        hipLaunchKernelGGL(partial_reduce_kernel<16>, dim3((2 * D + 15) / 16), dim3(256), 0, s, workspace, blocks, 2 * D,
+                           (int64_t)2 * D, dgamma, dbeta, D, accumulate);
+        THEIA_CHECK_LAUNCH("theia_layernorm_bwd(reduce)");
+        return THEIA_OK;
+    }
 #define LN_BWD_LAUNCH(TT, NVV, RR)                                                                                                      \
     if (q8.out != nullptr && sizeof(TT) == 2)                                                                                          \
         hipLaunchKernelGGL((ln_row_bwd_kernel<bf16_t, NVV, RR, true>), dim3(blocks), dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, \

@@ -1085,9 +1085,8 @@ class StudentEngine:
                                            q8=q8[:3] if q8 else None)
                 if train:
                     g, acc = self._grad(hm.adapter[idx].weight)
-                    ops.transpose_acc(tmp_g, g, hw * hw, C, acc)  # [HW][C] (NHWC reduction order) -> [C][H][W]
-                    g, acc = self._grad(hm.adapter[idx].bias)
-                    ops.transpose_acc(tmp_b, g, hw * hw, C, acc)
+                    gb_, accb_ = self._grad(hm.adapter[idx].bias)
+                    ops.transpose_acc2(tmp_g, g, acc, tmp_b, gb_, accb_, hw * hw, C)  # [HW][C] (NHWC reduction order) -> [C][H][W]
                 return dx
 
             def conv_dgrad(dy, wd_key, plan, out, resid=None, x8=None):

@@ -5,6 +5,7 @@ Everything here launches HIP kernels on torch's current stream; nothing falls ba
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -402,6 +403,9 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, grad_w: torch.Tensor, accumu
         colsum(dy, bias[0], bias[1], ws)
 
 
+_FINISH_GROUP = os.environ.get("THEIA_WGRAD_FINISH_GROUP", "1") != "0"  # A/B switch: 0 = one slab reduction per problem of a grouped launch
+
+
 def linear_wgrad_group(problems, ws: Optional[torch.Tensor] = None) -> None:
     """The weight and bias gradients of several nn.Linear layers that share M, as ONE weight-gradient launch (theia_gemm_wgrad_group: the
     split count is CUs / (all their tiles), so a small problem no longer runs 28 splits of its own) + one slab reduction each.
@@ -443,8 +447,15 @@ def linear_wgrad_group(problems, ws: Optional[torch.Tensor] = None) -> None:
             if e0 is not None:
                 WGRAD_PROFILE.append((e0, e1, sum(2.0 * M * q[2] * q[3] for q in parts), f"s{splits}g{len(parts)}",
                                       (M, sum(q[2] for q in parts), parts[0][3])))
-            for slabs, bslabs, Nn, K, gw, accw, gb, accb in parts:
-                wgrad_finish(slabs, splits, Nn, 1, K, gw, K, 0, 1, accw, (bslabs, gb, accb))
+            jobs = (N.WgradFinishJob * len(parts))()
+            for i, (slabs, bslabs, Nn, K, gw, accw, gb, accb) in enumerate(parts):
+                jobs[i] = N.WgradFinishJob(slabs.data_ptr(), gw.data_ptr(), bslabs.data_ptr(), gb.data_ptr(), K, Nn, K, int(accw), int(accb))
+            rc = N.lib().theia_wgrad_finish_group(jobs, len(parts), splits, N.stream_ptr()) if len(parts) > 1 and _FINISH_GROUP else N.ERR_UNSUPPORTED
+            if rc == N.ERR_UNSUPPORTED:  # (a gradient tensor that is not 16-byte aligned: one reduction per problem)
+                for slabs, bslabs, Nn, K, gw, accw, gb, accb in parts:
+                    wgrad_finish(slabs, splits, Nn, 1, K, gw, K, 0, 1, accw, (bslabs, gb, accb))
+            else:
+                N.check(rc, "theia_wgrad_finish_group")
             return
         if rc != N.ERR_UNSUPPORTED:
             N.check(rc, "theia_gemm_wgrad_group")
@@ -537,6 +548,12 @@ def unpermute3(src: torch.Tensor, dst: torch.Tensor, d0: int, d1: int, d2: int, 
                accumulate: bool) -> None:
     N.check(N.lib().theia_unpermute3_f32(src.data_ptr(), dst.data_ptr(), d0, d1, d2, t0, t1, t2, int(accumulate),
                                          N.stream_ptr()), "theia_unpermute3_f32")
+
+
+def transpose_acc2(src0: torch.Tensor, dst0: torch.Tensor, acc0: bool, src1: torch.Tensor, dst1: torch.Tensor, acc1: bool, R: int, Cc: int) -> None:
+    """transpose_acc of two [R, Cc] matrices by one launch"""
+    N.check(N.lib().theia_transpose_acc2_f32(src0.data_ptr(), dst0.data_ptr(), int(acc0), src1.data_ptr(), dst1.data_ptr(), int(acc1), R, Cc,
+                                             N.stream_ptr()), "theia_transpose_acc2_f32")
 
 
 def transpose_acc(src: torch.Tensor, dst: torch.Tensor, R: int, Cc: int, accumulate: bool) -> None:
