@@ -339,10 +339,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_kernel(const bf16_t* __
 // dQ, dK and dV of a head from ONE evaluation of S, P, dP and dS (the two-kernel form evaluates them twice), bit-reproducible:
 //   phase 0  Q and dO -> LDS, delta[q] = sum_d dO[q][d] * O[q][d] (8 lanes per row) -> LDS, lse -> LDS
 //   phase 1  a wave owns a 16-key tile (13 of the 16 waves): the dK / dV loop of the two-kernel form, and every dS tile it
-//            computes is also written to LDS as bf16 [query][key]
-//   phase 2  K -> LDS over Q; a wave owns a 16-query tile: dQ = dS K with dS read back from LDS as the packed k-slot-permuted
-//            operand the dQ kernel builds in registers -- a fixed summation order, no atomics.
-// LDS: Q, dO 2 x 31.5 KB + dS 208 x 456 B = 92.6 KB + lse / delta 1.8 KB = 157.4 KB: one 16-wave workgroup per CU (the same 16 waves
+//            computes is also written to LDS as bf16 [key][query] (8-byte writes)
+//   phase 2  K -> LDS over Q; a wave owns a 16-query tile: dQ = dS K with dS read back through the transposing LDS read as the
+//            k-slot-permuted operand the dQ kernel builds in registers -- a fixed summation order, no atomics.
+// LDS: Q, dO 2 x 31.5 KB + dS 208 x 464 B = 94.3 KB + lse / delta 1.8 KB = 159.0 KB: one 16-wave workgroup per CU (the same 16 waves
 // per CU as two 8-wave workgroups of the two-kernel form).
 __device__ __forceinline__ void am_unpack8(const uint4& a, float (&v)[8]) {
     const uint32_t w[4] = {a.x, a.y, a.z, a.w};
@@ -352,17 +352,26 @@ __device__ __forceinline__ void am_unpack8(const uint4& a, float (&v)[8]) {
         v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
     }
 }
-constexpr int AF_DS_PITCH = 456;   // bytes per dS row: 224 keys x 2 B + 8 (row starts fall on distinct even banks)
+constexpr int AF_DS_PITCH = 464;   // bytes per dS row ([key][query]): 224 queries x 2 B + 16 (16 rows x 16 B of a half-wave's write: 64 distinct banks)
 constexpr int AF_DS_ROWS = 208;
 constexpr int AF_THREADS = 1024;
 
+#ifdef AF_TRACE
+__device__ unsigned long long af_trace_buf[4096 * 8];
+#define AF_STAMP(i) do { if (threadIdx.x == 0) af_trace_buf[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+extern "C" int theia_debug_attn_trace(unsigned long long* out, int nblocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(af_trace_buf), (size_t)nblocks * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#else
+#define AF_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                     const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                     bf16_t* __restrict__ dqkv, int n, int h) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     char* sQ = sm;                                   // [224][144]; phase 2: K
     char* sG = sm + AM_ROWS * AM_PITCH;              // [224][144]  dO
-    char* sDS = sm + 2 * AM_ROWS * AM_PITCH;         // [208][456]  dS (bf16, scaled), keys 208..223 zero
+    char* sDS = sm + 2 * AM_ROWS * AM_PITCH;         // [208 keys][464]  dS (bf16, scaled), [key][query]
     float* sL = reinterpret_cast<float*>(sDS + AF_DS_ROWS * AF_DS_PITCH);   // [224] lse * log2e (+inf beyond n)
     float* sD = sL + AM_ROWS;                                              // [224] delta
     const int D = h * 64;
@@ -370,10 +379,13 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, g = lane >> 4;
-    if (tid < AF_DS_ROWS) {  // the key columns no wave writes (once: nothing else touches them)
-        *reinterpret_cast<uint4*>(sDS + tid * AF_DS_PITCH + 416) = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(sDS + tid * AF_DS_PITCH + 432) = make_uint4(0, 0, 0, 0);
+    AF_STAMP(0);
+#ifdef AF_TRACE
+    if (threadIdx.x == 0) {
+        af_trace_buf[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg(63492);
+        af_trace_buf[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(63508);
     }
+#endif
     // (A persistent form -- one workgroup per CU walking over heads, the next head's Q / dO / O and this head's K requested into
     //  registers ahead of time -- was measured: 172 us against 134 for this one; its 26 staging registers on top of phase 1 spill.)
     uint4 xq[2], xg[2], xo[2];
@@ -422,6 +434,7 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
             }
         }
         __syncthreads();
+        AF_STAMP(1);
         // this head's K pieces for phase 2, requested now
         uint4 xk[2];
 #pragma unroll
@@ -458,30 +471,23 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
                     am_mma(sa, am_nat(sQ, q0, 1, lane), kf[1]);
                     am_mma(da, am_nat(sG, q0, 0, lane), vf[0]);
                     am_mma(da, am_nat(sG, q0, 1, lane), vf[1]);
+                    // (the four rows' lse / delta as one 16-byte LDS read each: sixteen 4-byte reads per step were a third of the loop's LDS instructions)
+                    const float4 l4 = *reinterpret_cast<const float4*>(sL + q0 + g * 4), d4 = *reinterpret_cast<const float4*>(sD + q0 + g * 4);
+                    const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int qi = q0 + g * 4 + r;
-                        const float pv = kok ? am_exp2(fmaf(sa[r], AM_C, -sL[qi])) : 0.f;  // keys beyond n: no probability
+                        const float pv = kok ? am_exp2(fmaf(sa[r], AM_C, -lq[r])) : 0.f;  // keys beyond n: no probability
                         p[t][r] = pv;
-                        dsv[t][r] = pv * (da[r] - sD[qi]) * 0.125f;
+                        dsv[t][r] = pv * (da[r] - dq4[r]) * 0.125f;
                     }
                 }
                 const uint4 pb = am_pack(p[0], p[1]), sb = am_pack(dsv[0], dsv[1]);
-                // dS[q][k] for phase 2: this lane holds (q0 + 4g + r, key krow) -- sb.x/.y are tile t = 0 (r = 0,1 | 2,3), .z/.w tile t = 1
+                // dS for phase 2, stored [key][query]: this lane holds key krow x queries q0 + 4g + {0..3} (tile t = 0: sb.x/.y, t = 1: .z/.w) --
+                // two 8-byte writes (as [query][key] they were eight 2-byte ones); phase 2 reads it back through the transposing LDS read
                 {
-                    uint16_t* w0 = reinterpret_cast<uint16_t*>(sDS + krow * 2 + (32 * ks + g * 4) * AF_DS_PITCH);
-                    constexpr int rp = AF_DS_PITCH / 2;  // row pitch in 16-bit units
-                    w0[0 * rp] = (uint16_t)(sb.x & 0xffffu);
-                    w0[1 * rp] = (uint16_t)(sb.x >> 16);
-                    w0[2 * rp] = (uint16_t)(sb.y & 0xffffu);
-                    w0[3 * rp] = (uint16_t)(sb.y >> 16);
-                    if (2 * ks + 1 < AM_TILES) {  // (the 14th query tile does not exist)
-                        uint16_t* w1 = w0 + 16 * rp;
-                        w1[0 * rp] = (uint16_t)(sb.z & 0xffffu);
-                        w1[1 * rp] = (uint16_t)(sb.z >> 16);
-                        w1[2 * rp] = (uint16_t)(sb.w & 0xffffu);
-                        w1[3 * rp] = (uint16_t)(sb.w >> 16);
-                    }
+                    char* w0 = sDS + krow * AF_DS_PITCH + (32 * ks + g * 4) * 2;
+                    *reinterpret_cast<uint2*>(w0) = make_uint2(sb.x, sb.y);
+                    if (2 * ks + 1 < AM_TILES) *reinterpret_cast<uint2*>(w0 + 32) = make_uint2(sb.z, sb.w);  // (the 14th query tile does not exist)
                 }
 #pragma unroll
                 for (int df = 0; df < 4; ++df) {
@@ -498,7 +504,9 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
                 }
             }
         }
+        AF_STAMP(5);
         __syncthreads();  // every wave has finished reading Q / dO and writing dS
+        AF_STAMP(2);
         // ---- phase 2: K -> LDS (over Q), dQ = dS K
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -506,16 +514,24 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
             if (r < AM_ROWS) *reinterpret_cast<uint4*>(sQ + r * AM_PITCH + c * 16) = xk[it];
         }
         __syncthreads();
+        AF_STAMP(3);
         if (mytile < AM_TILES) {
             const int qrow = mytile * 16 + l16;
             am_f32x4 dq[4];
 #pragma unroll
             for (int df = 0; df < 4; ++df) dq[df] = (am_f32x4){0.f, 0.f, 0.f, 0.f};
-            const char* drow_l = sDS + qrow * AF_DS_PITCH + g * 8;
+            // dS[query tile][keys 32 ks + 4g + {0..3}, 32 ks + 16 + 4g + {0..3}] out of the [key][query] table: the transposing read of am_tr with
+            // the table's pitch (keys 208 .. 223 of the last step do not exist: zeros)
+            const char* dcol = sDS + (g * 4 + (l16 >> 2)) * AF_DS_PITCH + (mytile * 16 + (l16 & 3) * 4) * 2;
 #pragma unroll
             for (int ks = 0; ks < AM_KSTEPS; ++ks) {
-                const uint2 lo = *reinterpret_cast<const uint2*>(drow_l + ks * 64), hi2 = *reinterpret_cast<const uint2*>(drow_l + ks * 64 + 32);
-                const uint4 sb = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+                const am_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) am_s16x4*)(dcol + ks * 32 * AF_DS_PITCH));
+                uint2 h2 = make_uint2(0u, 0u);
+                if (ks * 32 + 16 < AF_DS_ROWS)
+                    h2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                       (__attribute__((address_space(3))) am_s16x4*)(dcol + (ks * 32 + 16) * AF_DS_PITCH)));
+                const uint2 l2 = __builtin_bit_cast(uint2, lo);
+                const uint4 sb = make_uint4(l2.x, l2.y, h2.x, h2.y);
 #pragma unroll
                 for (int df = 0; df < 4; ++df) am_mma(dq[df], am_tr(sQ, ks, df, lane), sb);
             }
@@ -525,6 +541,7 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
                 for (int df = 0; df < 4; ++df) am_store4(drow + df * 16, dq[df], 1.0f);
             }
         }
+        AF_STAMP(4);
     }
 }
 
