@@ -428,7 +428,7 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
                 *reinterpret_cast<uint4*>(sQ + r * AM_PITCH + c * 16) = xq[it];
                 *reinterpret_cast<uint4*>(sG + r * AM_PITCH + c * 16) = xg[it];
                 if (c == 0) {
-                    sD[r] = part;   // rows >= n: 0
+                    sD[r] = part * 0.125f;   // (pre-scaled with the softmax scale, see phase 1) rows >= n: 0
                     sL[r] = xl[it];  // rows >= n: +inf
                 }
             }
@@ -457,6 +457,17 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
                     vf[kk] = *reinterpret_cast<const uint4*>(base + krow * rs + 2 * D + kk * 32 + g * 8);
                 }
             }
+            // The per-score arithmetic is what bounds this loop (exp2 at quarter rate + 5 more issue slots per score, 8 scores per lane and
+            // tile), so everything that can leave it does.  dS = P (dP - delta) / 8: the 1/8 goes into V (dP = dO V^T) and delta, both exact
+            // (a power of two).  Keys beyond n need no select: their K and V fragments are zeros, so their P = exp2(-lse) and dS = -P delta / 8
+            // are finite, their dK / dV rows are not stored, and in dQ = dS K they meet the zero rows K is staged with.
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                float v8[8];
+                am_unpack8(vf[kk], v8);
+                vf[kk] = make_uint4(am_pack2(v8[0] * 0.125f, v8[1] * 0.125f), am_pack2(v8[2] * 0.125f, v8[3] * 0.125f),
+                                    am_pack2(v8[4] * 0.125f, v8[5] * 0.125f), am_pack2(v8[6] * 0.125f, v8[7] * 0.125f));
+            }
             am_f32x4 dk[4], dv[4];
 #pragma unroll
             for (int df = 0; df < 4; ++df) dk[df] = dv[df] = (am_f32x4){0.f, 0.f, 0.f, 0.f};
@@ -466,6 +477,10 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int q0 = (2 * ks + t) * 16;
+                    if (t == 1 && 2 * ks + 1 >= AM_TILES) {  // the 14th query tile does not exist (uniform; rows 208 .. 223: P = 0)
+                        p[1] = dsv[1] = (am_f32x4){0.f, 0.f, 0.f, 0.f};
+                        continue;
+                    }
                     am_f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
                     am_mma(sa, am_nat(sQ, q0, 0, lane), kf[0]);
                     am_mma(sa, am_nat(sQ, q0, 1, lane), kf[1]);
@@ -476,9 +491,9 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
                     const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pv = kok ? am_exp2(fmaf(sa[r], AM_C, -lq[r])) : 0.f;  // keys beyond n: no probability
+                        const float pv = am_exp2(fmaf(sa[r], AM_C, -lq[r]));
                         p[t][r] = pv;
-                        dsv[t][r] = pv * (da[r] - dq4[r]) * 0.125f;
+                        dsv[t][r] = pv * (da[r] - dq4[r]);
                     }
                 }
                 const uint4 pb = am_pack(p[0], p[1]), sb = am_pack(dsv[0], dsv[1]);
