@@ -358,7 +358,7 @@ constexpr int AF_THREADS = 1024;
 
 #ifdef AF_TRACE
 __device__ unsigned long long af_trace_buf[4096 * 8];
-#define AF_STAMP(i) do { if (threadIdx.x == 0) af_trace_buf[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define AF_STAMP(i) do { if (threadIdx.x == 0) af_trace_buf[(size_t)bh * 8 + (i)] = wall_clock64(); } while (0)  // (bh: the head in flight)
 extern "C" int theia_debug_attn_trace(unsigned long long* out, int nblocks) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(af_trace_buf), (size_t)nblocks * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
 }
@@ -367,7 +367,7 @@ extern "C" int theia_debug_attn_trace(unsigned long long* out, int nblocks) {
 #endif
 __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                     const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
-                                                                    bf16_t* __restrict__ dqkv, int n, int h) {
+                                                                    bf16_t* __restrict__ dqkv, int n, int h, int nheads) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     char* sQ = sm;                                   // [224][144]; phase 2: K
     char* sG = sm + AM_ROWS * AM_PITCH;              // [224][144]  dO
@@ -379,44 +379,69 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, g = lane >> 4;
-    AF_STAMP(0);
-#ifdef AF_TRACE
-    if (threadIdx.x == 0) {
-        af_trace_buf[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg(63492);
-        af_trace_buf[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(63508);
-    }
-#endif
-    // (A persistent form -- one workgroup per CU walking over heads, the next head's Q / dO / O and this head's K requested into
-    //  registers ahead of time -- was measured: 172 us against 134 for this one; its 26 staging registers on top of phase 1 spill.)
+    // PERSISTENT: a workgroup walks over heads blockIdx.x, + gridDim.x, ... (one workgroup per CU: the LDS holds one head), and a wave requests
+    // the NEXT head's Q / dO / O / lse pieces into registers as soon as its own phase-1 loop is done -- its phase-1 registers are dead then, the
+    // loads fly while it waits for the slowest wave, through the K staging and phase 2.  As one-head workgroups every CU spent 4.5 us per head
+    // waiting for these loads with the whole chip doing the same (the phase runs at HBM rate, then HBM idles for 12 us) + 2 us of workgroup
+    // turnaround (AF_TRACE stamps).  (Round 4 measured a persistent form that requested the next head AHEAD of phase 1: 172 us against 134,
+    // its 26 staging registers on top of phase 1's spilled.)
     uint4 xq[2], xg[2], xo[2];
+    uint4 nkf[2], nvf[2];  // the head's K / V fragments of this wave's key tile (phase 1), requested with its Q / dO / O pieces
     float xl[2];
-    const int bh = blockIdx.x;
-    {
-        const int bi = bh / h, hi = bh % h;
-        const bf16_t* base = qkv + (int64_t)bi * n * rs + hi * 64;
-        const bf16_t* gbase = d_o + (int64_t)bi * n * D + hi * 64;
-        const bf16_t* obase = o + (int64_t)bi * n * D + hi * 64;
+    // (Thread-index arithmetic inside the head loop starts from a value the compiler cannot see through: hoisted out of the loop, the per-thread
+    //  row offsets of the five staged matrices lived in registers across phase 1 and were spilled to scratch -- 148 bytes per lane.)
+    auto opaque_tid = [&]() {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        return t;
+    };
+    // (Branch-free: every load unconditional from a row clamped into the head, the head index clamped into the batch -- the last iteration
+    //  requests a head nobody uses.  Under a lane mask or a uniform `if` a load compiles to a branch, and where the sides meet the compiler
+    //  drains the memory counter (s_waitcnt vmcnt(0)): the requests would be waited for on the spot.  Rows beyond n become zeros in phase 0.)
+    auto request_head = [&](int bh_) {
+        const int tid_ = opaque_tid();
+        const bool more = bh_ < nheads;  // (behind the last head: every lane requests the first 16 bytes of a valid head -- one cache line per wave)
+        bh_ = more ? bh_ : nheads - 1;
+        const int bi_ = bh_ / h, hi_ = bh_ % h;
+        const bf16_t* base_ = qkv + (int64_t)bi_ * n * rs + hi_ * 64;
+        const bf16_t* gbase = d_o + (int64_t)bi_ * n * D + hi_ * 64;
+        const bf16_t* obase = o + (int64_t)bi_ * n * D + hi_ * 64;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            const int v = tid + it * AF_THREADS, r = v >> 3, c = v & 7;
-            xq[it] = xg[it] = xo[it] = make_uint4(0, 0, 0, 0);
-            xl[it] = INFINITY;
-            if (r < n && r < AM_ROWS) {
-                xq[it] = *reinterpret_cast<const uint4*>(base + r * rs + c * 8);
-                xg[it] = *reinterpret_cast<const uint4*>(gbase + (int64_t)r * D + c * 8);
-                xo[it] = *reinterpret_cast<const uint4*>(obase + (int64_t)r * D + c * 8);
-                if (c == 0) xl[it] = lse[(int64_t)bh * n + r] * AM_LOG2E;
-            }
+            const int v = more ? tid_ + it * AF_THREADS : 0, r = min(v >> 3, n - 1), c = v & 7;
+            xq[it] = *reinterpret_cast<const uint4*>(base_ + r * rs + c * 8);
+            xg[it] = *reinterpret_cast<const uint4*>(gbase + (int64_t)r * D + c * 8);
+            xo[it] = *reinterpret_cast<const uint4*>(obase + (int64_t)r * D + c * 8);
+            xl[it] = lse[(int64_t)bh_ * n + r];  // (scaled where it is used: a multiply here would wait for the load)
         }
-    }
-    {
+        const int krow_ = more ? min(((wave + bh_) & 15) * 16 + (tid_ & 15), n - 1) : 0;  // (idle waves / keys beyond n: a clamped row, zeroed at use)
+        const int g_ = more ? (tid_ & 63) >> 4 : 0;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            nkf[kk] = *reinterpret_cast<const uint4*>(base_ + krow_ * rs + D + kk * 32 + g_ * 8);
+            nvf[kk] = *reinterpret_cast<const uint4*>(base_ + krow_ * rs + 2 * D + kk * 32 + g_ * 8);
+        }
+    };
+    request_head(blockIdx.x);
+    for (int bh = blockIdx.x; bh < nheads; bh += gridDim.x) {
         const int bi = bh / h, hi = bh % h;
         const bf16_t* base = qkv + (int64_t)bi * n * rs + hi * 64;
+        AF_STAMP(0);
+#ifdef AF_TRACE
+        if (threadIdx.x == 0) {
+            af_trace_buf[(size_t)bh * 8 + 6] = __builtin_amdgcn_s_getreg(63492);
+            af_trace_buf[(size_t)bh * 8 + 7] = __builtin_amdgcn_s_getreg(63508);
+        }
+#endif
         // ---- phase 0: registers -> LDS, delta
+        const int tid0 = opaque_tid();
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            const int v = tid + it * AF_THREADS, r = v >> 3, c = v & 7;
+            const int v = tid0 + it * AF_THREADS, r = v >> 3, c = v & 7;
             float a8[8], b8[8], part = 0.f;
+            const bool live = r < n;  // (the pieces of rows beyond n were loaded from row n - 1)
+            xq[it] = am_keep(live, xq[it]);
+            xg[it] = am_keep(live, xg[it]);
             am_unpack8(xg[it], a8);
             am_unpack8(xo[it], b8);
 #pragma unroll
@@ -429,7 +454,7 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
                 *reinterpret_cast<uint4*>(sG + r * AM_PITCH + c * 16) = xg[it];
                 if (c == 0) {
                     sD[r] = part * 0.125f;   // (pre-scaled with the softmax scale, see phase 1) rows >= n: 0
-                    sL[r] = xl[it];  // rows >= n: +inf
+                    sL[r] = live ? xl[it] * AM_LOG2E : INFINITY;  // rows >= n: +inf
                 }
             }
         }
@@ -439,9 +464,8 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
         uint4 xk[2];
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            const int v = tid + it * AF_THREADS, r = v >> 3, c = v & 7;
-            xk[it] = make_uint4(0, 0, 0, 0);
-            if (r < n && r < AM_ROWS) xk[it] = *reinterpret_cast<const uint4*>(base + r * rs + D + c * 8);
+            const int v = tid0 + it * AF_THREADS, r = v >> 3, c = v & 7;
+            xk[it] = *reinterpret_cast<const uint4*>(base + min(r, n - 1) * rs + D + c * 8);  // (rows beyond n: zeroed when staged)
         }
         const int mytile = (wave + bh) & 15;  // 13 of the 16 waves own a tile; which three idle rotates with the head
         // ---- phase 1: dK, dV (+ dS -> LDS)
@@ -451,11 +475,8 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
             uint4 kf[2], vf[2];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                kf[kk] = vf[kk] = make_uint4(0, 0, 0, 0);
-                if (kok) {
-                    kf[kk] = *reinterpret_cast<const uint4*>(base + krow * rs + D + kk * 32 + g * 8);
-                    vf[kk] = *reinterpret_cast<const uint4*>(base + krow * rs + 2 * D + kk * 32 + g * 8);
-                }
+                kf[kk] = am_keep(kok, nkf[kk]);
+                vf[kk] = am_keep(kok, nvf[kk]);
             }
             // The per-score arithmetic is what bounds this loop (exp2 at quarter rate + 5 more issue slots per score, 8 scores per lane and
             // tile), so everything that can leave it does.  dS = P (dP - delta) / 8: the 1/8 goes into V (dP = dO V^T) and delta, both exact
@@ -519,14 +540,16 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
                 }
             }
         }
+        request_head(bh + (int)gridDim.x);  // the next head's pieces: see the top of the loop
         AF_STAMP(5);
         __syncthreads();  // every wave has finished reading Q / dO and writing dS
         AF_STAMP(2);
         // ---- phase 2: K -> LDS (over Q), dQ = dS K
+        const int tid2 = opaque_tid();
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            const int v = tid + it * AF_THREADS, r = v >> 3, c = v & 7;
-            if (r < AM_ROWS) *reinterpret_cast<uint4*>(sQ + r * AM_PITCH + c * 16) = xk[it];
+            const int v = tid2 + it * AF_THREADS, r = v >> 3, c = v & 7;
+            if (r < AM_ROWS) *reinterpret_cast<uint4*>(sQ + r * AM_PITCH + c * 16) = am_keep(r < n, xk[it]);
         }
         __syncthreads();
         AF_STAMP(3);
@@ -557,6 +580,7 @@ __global__ __launch_bounds__(AF_THREADS) void attn_bwd_fused_kernel(const bf16_t
             }
         }
         AF_STAMP(4);
+        __syncthreads();  // phase 2 has read K (over Q) and dS: the next head's phase 0 may overwrite them
     }
 }
 
@@ -590,8 +614,9 @@ int theia_attention_bwd_mfma(const void* qkv, const void* o, const void* d_o, co
     if (fused) {
         const int ldsf = 2 * AM_ROWS * AM_PITCH + AF_DS_ROWS * AF_DS_PITCH + 2 * AM_ROWS * (int)sizeof(float);
         am_set_lds(reinterpret_cast<const void*>(attn_bwd_fused_kernel), ldsf);
-        hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(b * h), dim3(AF_THREADS), ldsf, s, (const bf16_t*)qkv, (const bf16_t*)o,
-                           (const bf16_t*)d_o, lse, (bf16_t*)dqkv, n, h);
+        const int cus = theia_compute_cus();
+        hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(b * h < cus ? b * h : cus), dim3(AF_THREADS), ldsf, s, (const bf16_t*)qkv, (const bf16_t*)o,
+                           (const bf16_t*)d_o, lse, (bf16_t*)dqkv, n, h, b * h);
         THEIA_CHECK_LAUNCH("theia_attention_bwd(fused mfma)");
         return THEIA_OK;
     }

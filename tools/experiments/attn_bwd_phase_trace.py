@@ -31,8 +31,8 @@ assert lib.theia_debug_attn_trace(buf, nb) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 8).astype(np.int64)
 us = lambda x: x / 100.0  # wall_clock64: 100 MHz
 t0 = t[:, 0].min()
-print(f"workgroups {nb}; kernel span {us(t[:, 4].max() - t0):.1f} us")
-names = ["loads landed + phase 0 (t1 - t0)", "phase 1 of wave 0 (t5 - t1)", "wait for the slowest wave (t2 - t5)", "K -> LDS (t3 - t2)", "phase 2 + dq stores issued (t4 - t3)"]
+print(f"heads {nb}; kernel span {us(t[:, 4].max() - t0):.1f} us")
+names = ["wait for the requested pieces + phase 0 (t1 - t0)", "phase 1 of wave 0 (t5 - t1)", "wait for the slowest wave (t2 - t5)", "K -> LDS (t3 - t2)", "phase 2 + dq stores issued (t4 - t3)"]
 pairs = [(0, 1), (1, 5), (5, 2), (2, 3), (3, 4)]
 for nm, (i, j) in zip(names, pairs):
     d = us(t[:, j] - t[:, i])
@@ -49,4 +49,4 @@ for k in np.unique(key):
     gaps += list(us(rows[1:, 0] - rows[:-1, 4]))
 gaps = np.array(gaps)
 print(f"  distinct (xcc, se/sh/cu) ids {len(per_cu)}, workgroups per id {min(per_cu)}..{max(per_cu)}")
-print(f"  gap between a workgroup's last stamp and the next one's first on the same id: mean {gaps.mean():.2f}  p10 {np.percentile(gaps, 10):.2f}  p90 {np.percentile(gaps, 90):.2f} us")
+print(f"  gap between a head's last stamp and the next head's first on the same CU (the loop-end barrier): mean {gaps.mean():.2f}  p10 {np.percentile(gaps, 10):.2f}  p90 {np.percentile(gaps, 90):.2f} us")
