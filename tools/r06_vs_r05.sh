@@ -18,7 +18,7 @@ for r in 1 2 3; do
   run base_r06 . $r
   run base_r06_fp32_targets . $r --teacher-dtype fp32
 done
-for r in ; do
+for r in 1 2; do
   run small_r05 build/r05_tree $r --backbone facebook/deit-small-patch16-224 --batch 256
   run small_r06 . $r --backbone facebook/deit-small-patch16-224 --batch 256
   run tiny_r05 build/r05_tree $r --backbone facebook/deit-tiny-patch16-224 --teachers cdiv --batch 256
