@@ -618,19 +618,31 @@ __global__ __launch_bounds__(256) void chw_apply_kernel(const T* __restrict__ x,
         load8(gamma + e, g8);
         load8(beta + e, b8);
     }
+    __shared__ float2 st[256];  // SUMS: (mean, rstd) of up to 256 samples of the group, derived once per block (one sample per thread) --
+    // as part of the sample loop every lane repeated the f64 division and square root for every sample: more VALU work than the 8 elements
     for (int sample = s0; sample < s1; ++sample) {
         float mu, rs;
         if constexpr (SUMS) {  // 2^-24 fixed-point 64-bit sums (GEMM epilogues)
-            const long long* fx = reinterpret_cast<const long long*>(stats);
-            const double m = (double)fx[2 * sample] * (1.0 / 16777216.0) / (double)E;
-            double var = (double)fx[2 * sample + 1] * (1.0 / 16777216.0) / (double)E - m * m;
-            if (var < 0.0) var = 0.0;
-            mu = (float)m;
-            rs = (float)(1.0 / sqrt(var + (double)eps));
-            if (blockIdx.x == 0 && threadIdx.x == 0) {
-                stats_out[2 * sample] = mu;
-                stats_out[2 * sample + 1] = rs;
+            const int w = (sample - s0) & 255;
+            if (w == 0) {
+                __syncthreads();  // (the previous window has been read)
+                const int mine = sample + (int)threadIdx.x;
+                if (mine < s1) {
+                    const long long* fx = reinterpret_cast<const long long*>(stats);
+                    const double m = (double)fx[2 * mine] * (1.0 / 16777216.0) / (double)E;
+                    double var = (double)fx[2 * mine + 1] * (1.0 / 16777216.0) / (double)E - m * m;
+                    if (var < 0.0) var = 0.0;
+                    const float2 v = make_float2((float)m, (float)(1.0 / sqrt(var + (double)eps)));
+                    st[threadIdx.x] = v;
+                    if (blockIdx.x == 0) {
+                        stats_out[2 * mine] = v.x;
+                        stats_out[2 * mine + 1] = v.y;
+                    }
+                }
+                __syncthreads();
             }
+            mu = st[w].x;
+            rs = st[w].y;
         } else {
             mu = stats[2 * sample];
             rs = stats[2 * sample + 1];
