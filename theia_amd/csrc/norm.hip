@@ -524,27 +524,32 @@ __global__ __launch_bounds__(256) void chw_partial_kernel(const T* __restrict__ 
             rs = stats[2 * sample + 1];
         }
         float sa = 0.f, sb = 0.f;
+        // every piece of the sample's chunk requested first, unconditionally (pieces past E: from the last valid vector, masked below) -- under
+        // `if (e < E)` each piece was a branch with its own load -> s_waitcnt vmcnt(0) -> use (see ln_row_fwd_kernel)
+        float xv[IT][8], dv[MODE == 1 ? IT : 1][8];
+        bool okv[IT];
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int64_t e = (int64_t)chunk * CHW_CHUNK + (it * 256 + threadIdx.x) * 8;
-            if (e < E) {
-                float xv[8];
-                load8(x + base + e, xv);
-                if (MODE == 0) {
+            okv[it] = e < E;
+            const int64_t ec = okv[it] ? e : E - 8;
+            load8(x + base + ec, xv[it]);
+            if (MODE == 1) load8(dy + base + ec, dv[MODE == 1 ? it : 0]);
+        }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        sa += xv[j];
-                        sb += xv[j] * xv[j];
-                    }
-                } else {
-                    float dv[8];
-                    load8(dy + base + e, dv);
+        for (int it = 0; it < IT; ++it) {
+            if (MODE == 0) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float gy = dv[j] * g8[MODE == 1 ? it : 0][j];
-                        sa += gy;
-                        sb += gy * (xv[j] - mu) * rs;
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    sa += okv[it] ? xv[it][j] : 0.f;
+                    sb += okv[it] ? xv[it][j] * xv[it][j] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gy = dv[MODE == 1 ? it : 0][j] * g8[MODE == 1 ? it : 0][j];
+                    sa += okv[it] ? gy : 0.f;
+                    sb += okv[it] ? gy * (xv[it][j] - mu) * rs : 0.f;
                 }
             }
         }
